@@ -1,0 +1,135 @@
+"""Pin the CPU oracle against vectors produced by the REFERENCE's own functions
+(tests/golden/make_golden.py, run in the build container) and against the reference's stored
+outputs.  No GPU needed."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ftp_oracle as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def g():
+    return np.load(os.path.join(G, "ref_numpy_small.npz"))
+
+
+def test_roi_helpers(g):
+    assert tuple(g["circle3"]) == (2012, 1129, 591)
+    assert tuple(g["circle3"]) == O.circle_from_3_points((1873, 1703), (1599, 707), (2575, 950))
+    assert np.array_equal(g["mask_64"], O.circular_mask(64, 72, 35, 31, 28))
+    assert np.array_equal(g["apo_64"], O.circular_apodization(64, 72, 35, 31, 28, 9))
+    assert np.array_equal(g["apo_64_bigtaper"], O.circular_apodization(64, 72, 35, 31, 28, 40))
+
+
+def test_fft_peak_search(g):
+    mag = g["peaks_mag"]
+    peaks = O.find_top_peaks(mag, 10, 12)
+    assert np.array_equal(np.array(peaks, dtype=np.float64), g["peaks_top12"])
+    px, py = O.choose_carrier_peak(peaks, *mag.shape)
+    assert (px, py) == tuple(g["peaks_chosen"])
+    assert np.array_equal(np.array(O.refine_peak_parabolic_log(mag, px, py)), g["peaks_refined"])
+    assert np.array_equal(O.hann_patch_window(21, 21), g["hann_21"])
+
+
+def test_unwrap_matches_reference_loop(g):
+    for qk, ok in (("uw_quality", "uw_out"), ("uw_quality_ties", "uw_out_ties")):
+        ref = g[ok]
+        got = O.unwrap_quality_guided(g["uw_wrapped"], g["uw_mask"], g[qk])
+        assert np.array_equal(np.isnan(ref), np.isnan(got))
+        m = ~np.isnan(ref)
+        # same flood order and parents; float32 sin/cos/atan2 may differ from NumPy's by an ulp per step
+        assert np.max(np.abs(ref[m] - got[m])) < 2e-5
+        # integer wrap counts identical
+        k_ref = np.rint((ref[m] - g["uw_wrapped"][m]) / (2 * np.pi))
+        k_got = np.rint((got[m] - g["uw_wrapped"][m]) / (2 * np.pi))
+        assert np.array_equal(k_ref, k_got)
+        py = O.unwrap_quality_guided_py(g["uw_wrapped"], g["uw_mask"], g[qk])
+        assert np.array_equal(py, ref, equal_nan=True)
+    got = O.unwrap_quality_guided(g["uw_wrapped"], np.zeros_like(g["uw_mask"]), g["uw_quality"])
+    assert np.all(np.isnan(got)) and np.all(np.isnan(g["uw_out_empty"]))
+
+
+def test_robust_polyfit(g):
+    for order, ck, fk in ((2, "pf_coef2", "pf_fit2"), (1, "pf_coef1", "pf_fit1")):
+        c, f = O.robust_polyfit2d(g["pf_z"], g["pf_mask"], order=order)
+        assert np.array_equal(c, g[ck]) and np.array_equal(f, g[fk])
+    yy, xx = np.mgrid[0:80, 0:80]
+    c, f = O.robust_polyfit2d(g["pf_z"], g["pf_mask"] & (xx < 5) & (yy < 5), order=2)
+    assert np.array_equal(c, g["pf_coef_small"]) and np.array_equal(f, g["pf_fit_small"])
+
+
+def test_stats_and_curves(g):
+    v = g["st_v"]
+    got = np.array([O.nanpercentile_safe(v, q) for q in (8.0, 25.0, 92.0, 95, 98, 99.7, 99.9)])
+    assert np.array_equal(got, g["st_pcts"])
+    assert np.array_equal(np.array([O.nanmedian_safe(v), O.nanmedian_safe(v[:500])]), g["st_median"])
+    cal, use_neg = O.load_calibration(os.path.join(G, "calibration_phase_to_height.json"))
+    assert np.array_equal(O.height_unitless_to_depth_mm(g["mm_in"], cal, use_neg), g["mm_out"])
+    assert np.array_equal(O.model_predict({"type": "growth", "params": {"a": 1.5, "b": 2.0}}, g["mm_in"]), g["mm_growth"])
+    assert np.array_equal(O._smoothstep01(g["curve_t"]), g["curve_smooth"])
+    assert np.array_equal(O.clamp_positive_to_zero(g["clamp_in"], np.ones_like(g["clamp_in"], bool)),
+                          g["clamp_out"], equal_nan=True)
+    with pytest.raises(ValueError):
+        O.model_predict({"type": "nope", "params": {}}, g["mm_in"])
+
+
+def test_force_tail(g):
+    h = g["tail_h"]
+    roi = np.isfinite(h)
+    assert np.array_equal(np.array(O.depth_map_to_volume_cm3(h, roi, 0.0303784, 0.01)), g["tail_res"])
+    assert np.array_equal(np.array(O.depth_map_to_volume_cm3(-h, roi, 0.0303784, 0.01)), g["tail_res_neg"])
+    assert np.array_equal(np.array(O.depth_map_to_volume_cm3(h * 0, roi, 0.0303784, 0.01)), g["tail_res_empty"])
+    best = json.load(open(os.path.join(G, "calibration_height_to_force.json")))["best_model"]
+    got = np.array([O.predict_force_from_volume(best, v) for v in g["force_vols"]])
+    assert np.array_equal(got, g["force_growth"])
+    for t, p in (("linear0", {"a": 2.0}), ("linear", {"a": 2.0, "b": 0.5}), ("poly2", {"c2": 1.0, "c1": 2.0, "c0": 0.1}),
+                 ("sat_exp", {"a": 3.0, "b": 4.0}), ("hinge_saturating", {"a": 3.0, "b": 4.0, "c": 0.05})):
+        got = np.array([O.predict_force_from_volume({"type": t, "params": p}, v) for v in g["force_vols"]])
+        assert np.array_equal(got, g[f"force_{t}"])
+    assert O.estimate_mm_per_px(65.83619546657023) == g["mm_per_px"][0]
+    with pytest.raises(RuntimeError):
+        O.estimate_mm_per_px(None)
+    with pytest.raises(RuntimeError):
+        O.estimate_mm_per_px(0.0)
+    with pytest.raises(ValueError):
+        O.predict_force_from_volume({"type": "nope", "params": {}}, 0.1)
+
+
+def test_tail_on_decimated_stored_demo():
+    d = np.load(os.path.join(G, "ref_tail_demo_E_small.npz"))
+    h = d["height"]
+    got = O.depth_map_to_volume_cm3(h, np.isfinite(h), float(d["mm_per_px"][0]), 0.01)
+    assert np.array_equal(np.array(got), d["tail"])
+
+
+def test_stored_demo_tails_reproduced():
+    """The reference's own tail on its stored bundles reproduces its stored result.json
+    (area / max depth exactly, volume / force to float32-sum precision) -- recorded by make_golden.py."""
+    meta = json.load(open(os.path.join(G, "ref_tail_demos.json")))
+    assert len(meta["demos"]) == 5
+    for name, d in meta["demos"].items():
+        s, r = d["stored"], d["reference_tail_on_bundle"]
+        assert s["contact_area_mm2"] == r["contact_area_mm2"], name
+        assert s["max_depth_mm"] == r["max_depth_mm"], name
+        assert abs(s["volume_cm3"] - r["volume_cm3"]) <= 1e-7 * s["volume_cm3"], name
+        assert abs(s["force_N"] - r["force_N"]) <= 1e-6 * s["force_N"], name
+        assert s["estimated_grating_period_px"] == 65.83619546657023
+        assert O.estimate_mm_per_px(s["estimated_grating_period_px"]) == s["mm_per_px"]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/Multimodal_Sensor"), reason="reference tree not mounted")
+def test_oracle_tail_on_full_stored_bundles():
+    meta = json.load(open(os.path.join(G, "ref_tail_demos.json")))
+    best = meta["force_model"]
+    for name, d in meta["demos"].items():
+        b = np.load(f"/root/reference/Multimodal_Sensor/Demos_report/{name}/force_sensing/ftp_run/height_map_bundle.npz")
+        h = b["height_crop"]
+        v, a, md = O.depth_map_to_volume_cm3(h, np.isfinite(h), d["stored"]["mm_per_px"], 0.01)
+        r = d["reference_tail_on_bundle"]
+        assert (v, a, md) == (r["volume_cm3"], r["contact_area_mm2"], r["max_depth_mm"])
+        assert O.predict_force_from_volume(best, v) == r["force_N"]
+        assert O.argmax_depth_mm(h, b["crop_roi_eroded"]) == d["argmax_depth_index"]
