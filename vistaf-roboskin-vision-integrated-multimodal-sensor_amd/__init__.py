@@ -1,0 +1,15 @@
+"""MI355X-native (gfx950) implementation of the VISTAF image -> height-map -> force path.
+
+Drop-in for the Fourier-Transform-Profilometry hot path of
+rimelq/VISTAF-RoboSkin-Vision-Integrated-Multimodal-Sensor (Code/shape_ftp.py + the force tail of
+Code/force_sensor.py).  All image arithmetic runs in hand-written HIP kernels behind the C ABI of
+include/vistaf_ftp.h; this package is the thin Python host side.  There is no CPU fallback.
+"""
+from . import _lib
+from .config import FtpConfig
+from .ftp import (FtpSensor, SCALAR_NAMES, depth_map_to_volume_cm3, estimate_mm_per_px, load_calibration,
+                  load_force_calibration, predict, predict_force_from_volume)
+from . import synth
+
+__all__ = ["FtpConfig", "FtpSensor", "SCALAR_NAMES", "depth_map_to_volume_cm3", "estimate_mm_per_px", "load_calibration",
+           "load_force_calibration", "predict", "predict_force_from_volume", "synth", "_lib"]

@@ -1,0 +1,238 @@
+// Per-pixel / stencil kernels of the FTP preprocessing (bandwidth-bound; planes are [B, h, w]).
+//   to_gray        cv2.cvtColor(BGR2GRAY) fixed point          (shape_ftp.py:1511-1512)
+//   sobel_mag      cv2.Sobel x/y ksize 3 + magnitude            (shape_ftp.py:633-635)
+//   bad_flags      (img >= hi) | (grad >= g) & valid            (shape_ftp.py:638-639)
+//   morph          cv2.dilate / erode with ELLIPSE element      (shape_ftp.py:644-646, :758-760, :1734-1736)
+//   gauss_rows/cols cv2.GaussianBlur((0,0), sigma) REFLECT_101  (shape_ftp.py:746, :831, :836, :1145-1146)
+//   illum_norm     I/(blur+1e-6) - 1                            (shape_ftp.py:832)
+#include "kernels.hpp"
+
+namespace vf {
+
+// ------------------------------------------------------------------------------------------------
+__global__ void k_to_gray(const void *__restrict__ frames, int format, float *__restrict__ gray, int P)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    size_t b = blockIdx.y;
+    if (p >= P) return;
+    size_t i = b * (size_t)P + p;
+    float v;
+    if (format == 0) v = (float)((const uint8_t *)frames)[i];
+    else if (format == 2) v = rintf(__half2float(((const __half *)frames)[i]));
+    else {
+        int bb, gg, rr;
+        if (format == 1) { const uint8_t *s = (const uint8_t *)frames + 3 * i; bb = s[0]; gg = s[1]; rr = s[2]; }
+        else { const __half *s = (const __half *)frames + 3 * i; bb = (int)rintf(__half2float(s[0])); gg = (int)rintf(__half2float(s[1])); rr = (int)rintf(__half2float(s[2])); }
+        // OpenCV 4.x RGB2Gray 8u: descale(b*BY15 + g*GY15 + r*RY15, 15), BY15=3735 GY15=19235 RY15=9798
+        v = (float)((bb * 3735 + gg * 19235 + rr * 9798 + (1 << 14)) >> 15);
+    }
+    gray[i] = v;
+}
+
+void launch_to_gray(const void *frames, int format, float *gray, int B, int P, hipStream_t st)
+{
+    dim3 grid((P + 255) / 256, B);
+    hipLaunchKernelGGL(k_to_gray, grid, dim3(256), 0, st, frames, format, gray, P);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void k_sobel_mag(const float *__restrict__ img, float *__restrict__ grad, int h, int w)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y;
+    size_t b = blockIdx.z;
+    if (x >= w) return;
+    const float *s = img + b * (size_t)h * w;
+    int ym = reflect101(y - 1, h), yp = reflect101(y + 1, h), xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
+    float a00 = s[(size_t)ym * w + xm], a01 = s[(size_t)ym * w + x], a02 = s[(size_t)ym * w + xp];
+    float a10 = s[(size_t)y * w + xm], a12 = s[(size_t)y * w + xp];
+    float a20 = s[(size_t)yp * w + xm], a21 = s[(size_t)yp * w + x], a22 = s[(size_t)yp * w + xp];
+    float gx = __fadd_rn(__fadd_rn(__fsub_rn(a02, a00), __fmul_rn(2.0f, __fsub_rn(a12, a10))), __fsub_rn(a22, a20));
+    float gy = __fadd_rn(__fadd_rn(__fsub_rn(a20, a00), __fmul_rn(2.0f, __fsub_rn(a21, a01))), __fsub_rn(a22, a02));
+    grad[b * (size_t)h * w + (size_t)y * w + x] = __fsqrt_rn(__fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy)));
+}
+
+void launch_sobel_mag(const float *img, float *grad, int B, int h, int w, hipStream_t st)
+{
+    dim3 grid((w + 255) / 256, h, B);
+    hipLaunchKernelGGL(k_sobel_mag, grid, dim3(256), 0, st, img, grad, h, w);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void k_bad_flags(const float *__restrict__ img, const float *__restrict__ grad, const uint8_t *__restrict__ valid,
+                            const float *__restrict__ thr_hi, const float *__restrict__ thr_g, uint8_t *__restrict__ bad, int P)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    size_t b = blockIdx.y;
+    if (p >= P) return;
+    size_t i = b * (size_t)P + p;
+    bad[i] = (uint8_t)(valid[p] && ((img[i] >= thr_hi[b]) || (grad[i] >= thr_g[b])));
+}
+
+void launch_bad_flags(const float *img, const float *grad, const uint8_t *valid, const float *thr_hi, const float *thr_g,
+                      uint8_t *bad, int B, int P, hipStream_t st)
+{
+    dim3 grid((P + 255) / 256, B);
+    hipLaunchKernelGGL(k_bad_flags, grid, dim3(256), 0, st, img, grad, valid, thr_hi, thr_g, bad, P);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Binary dilate / erode, element given as row spans; out-of-image pixels never contribute
+// (cv::morphologyDefaultBorderValue).  Optional AND with a static [P] and/or a per-frame [B,P] mask.
+__global__ void k_morph(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int h, int w, RowSpanSE se, int dilate,
+                        const uint8_t *__restrict__ and_static, const uint8_t *__restrict__ and_frame)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y;
+    size_t b = blockIdx.z;
+    if (x >= w) return;
+    const uint8_t *s = src + b * (size_t)h * w;
+    int r = se.k / 2;
+    int v = dilate ? 0 : 1;
+    for (int i = 0; i < se.k; i++) {
+        int yy = y + i - r;
+        if (yy < 0 || yy >= h) continue;
+        int x0 = x + se.lo[i], x1 = x + se.hi[i];
+        if (x0 < 0) x0 = 0;
+        if (x1 > w - 1) x1 = w - 1;
+        const uint8_t *row = s + (size_t)yy * w;
+        if (dilate) {
+            for (int xx = x0; xx <= x1; xx++) if (row[xx]) { v = 1; break; }
+            if (v) break;
+        } else {
+            for (int xx = x0; xx <= x1; xx++) if (!row[xx]) { v = 0; break; }
+            if (!v) break;
+        }
+    }
+    size_t p = (size_t)y * w + x;
+    if (and_static && !and_static[p]) v = 0;
+    if (and_frame && !and_frame[b * (size_t)h * w + p]) v = 0;
+    dst[b * (size_t)h * w + p] = (uint8_t)v;
+}
+
+void launch_morph(const uint8_t *src, uint8_t *dst, int B, int h, int w, const RowSpanSE &se, bool dilate,
+                  const uint8_t *and_static, const uint8_t *and_frame, hipStream_t st)
+{
+    dim3 grid((w + 255) / 256, h, B);
+    hipLaunchKernelGGL(k_morph, grid, dim3(256), 0, st, src, dst, h, w, se, dilate ? 1 : 0, and_static, and_frame);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Separable Gaussian, BORDER_REFLECT_101.  Row pass: 64-column x 4-row tile staged in LDS with halo.
+constexpr int GB_TX = 64, GB_TY = 4, GB_MAXK = 512;
+
+__global__ __launch_bounds__(256) void k_gauss_rows(const float *__restrict__ src, float *__restrict__ dst,
+                                                    const float *__restrict__ kern, int ksize, int h, int w)
+{
+    extern __shared__ float lds[];
+    int r = ksize / 2;
+    int tw = GB_TX + 2 * r;
+    float *kk = lds;                    // ksize taps
+    float *tile = lds + GB_MAXK;        // GB_TY rows of tw
+    int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    int x0 = blockIdx.x * GB_TX, y = blockIdx.y * GB_TY + ty;
+    size_t b = blockIdx.z;
+    for (int i = threadIdx.x; i < ksize; i += 256) kk[i] = kern[i];
+    if (y < h) {
+        const float *row = src + b * (size_t)h * w + (size_t)y * w;
+        for (int i = tx; i < tw; i += 64) tile[ty * tw + i] = row[reflect101(x0 + i - r, w)];
+    }
+    __syncthreads();
+    int x = x0 + tx;
+    if (y >= h || x >= w) return;
+    const float *t = tile + ty * tw + tx;
+    float acc = kk[0] * t[0];
+    for (int j = 1; j < ksize; j++) acc = fmaf(kk[j], t[j], acc);
+    dst[b * (size_t)h * w + (size_t)y * w + x] = acc;
+}
+
+// Column pass: each thread produces GC_R consecutive rows of one column (sliding window in registers),
+// lanes run along x so every tap is a coalesced row read.
+constexpr int GC_R = 8;
+
+__global__ __launch_bounds__(256) void k_gauss_cols(const float *__restrict__ src, float *__restrict__ dst,
+                                                    const float *__restrict__ kern, int ksize, int h, int w)
+{
+    __shared__ float kk[GB_MAXK];
+    for (int i = threadIdx.x; i < ksize; i += 256) kk[i] = kern[i];
+    __syncthreads();
+    int r = ksize / 2;
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * GC_R;
+    size_t b = blockIdx.z;
+    if (x >= w || y0 >= h) return;
+    const float *s = src + b * (size_t)h * w;
+    float acc[GC_R];
+#pragma unroll
+    for (int o = 0; o < GC_R; o++) acc[o] = 0.f;
+    for (int j = 0; j < ksize + GC_R - 1; j++) {
+        float v = s[(size_t)reflect101(y0 + j - r, h) * w + x];
+#pragma unroll
+        for (int o = 0; o < GC_R; o++) {
+            int t = j - o;
+            if (t >= 0 && t < ksize) acc[o] = fmaf(kk[t], v, acc[o]);
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < GC_R; o++)
+        if (y0 + o < h) dst[b * (size_t)h * w + (size_t)(y0 + o) * w + x] = acc[o];
+}
+
+void launch_gauss_rows(const float *src, float *dst, const float *kern, int ksize, int B, int h, int w, hipStream_t st)
+{
+    dim3 grid((w + GB_TX - 1) / GB_TX, (h + GB_TY - 1) / GB_TY, B);
+    size_t lds = (GB_MAXK + (size_t)GB_TY * (GB_TX + 2 * (ksize / 2))) * sizeof(float);
+    hipLaunchKernelGGL(k_gauss_rows, grid, dim3(256), lds, st, src, dst, kern, ksize, h, w);
+}
+
+void launch_gauss_cols(const float *src, float *dst, const float *kern, int ksize, int B, int h, int w, hipStream_t st)
+{
+    dim3 grid((w + 63) / 64, (h + 4 * GC_R - 1) / (4 * GC_R), B);
+    hipLaunchKernelGGL(k_gauss_cols, grid, dim3(256), 0, st, src, dst, kern, ksize, h, w);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void k_illum_norm(const float *__restrict__ img, const float *__restrict__ blur, float *__restrict__ out, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // float32: img / (blur + 1e-6) - 1.0
+    out[i] = __fsub_rn(__fdiv_rn(img[i], __fadd_rn(blur[i], 1e-6f)), 1.0f);
+}
+void launch_illum_norm(const float *img, const float *blur, float *out, int B, int P, hipStream_t st)
+{
+    size_t n = (size_t)B * P;
+    hipLaunchKernelGGL(k_illum_norm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, img, blur, out, n);
+}
+
+__global__ void k_mul_static(const float *__restrict__ a, const float *__restrict__ stat, float *__restrict__ out, int P)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    size_t b = blockIdx.y;
+    if (p >= P) return;
+    out[b * (size_t)P + p] = __fmul_rn(a[b * (size_t)P + p], stat[p]);
+}
+void launch_mul_static(const float *a, const float *stat, float *out, int B, int P, hipStream_t st)
+{
+    dim3 grid((P + 255) / 256, B);
+    hipLaunchKernelGGL(k_mul_static, grid, dim3(256), 0, st, a, stat, out, P);
+}
+
+__global__ void k_count_u8(const uint8_t *__restrict__ m, int *__restrict__ counts, int P)
+{
+    __shared__ int scratch[16];
+    size_t b = blockIdx.y;
+    int c = 0;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) c += m[b * (size_t)P + p] != 0;
+    c = block_sum<int>(c, scratch);
+    if (threadIdx.x == 0 && c) atomicAdd(&counts[b], c);
+}
+void launch_count_u8(const uint8_t *m, int *counts, int B, int P, hipStream_t st)
+{
+    hipMemsetAsync(counts, 0, sizeof(int) * B, st);
+    int gx = (P + 256 * 16 - 1) / (256 * 16);
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(k_count_u8, dim3(gx, B), dim3(256), 0, st, m, counts, P);
+}
+
+}  // namespace vf

@@ -1,0 +1,203 @@
+// Mask topology kernels: thresholding, 8-connected components (union-find), largest component,
+// exact 3x3 chamfer distance transform.
+//   threshold_mask   roi & (q >= thr) & isfinite(q)                       (shape_ftp.py:753)
+//   cc_label         cv2.connectedComponentsWithStats(connectivity=8)     (shape_ftp.py:712, :1244)
+//   cc_largest       labels == 1 + argmax(areas)                           (shape_ftp.py:716-718)
+//   chamfer          cv2.distanceTransform(DIST_L2, 3)                     (shape_ftp.py:725, :1309, :1312)
+//
+// One 1024-thread workgroup owns one frame, so every union-find word is only touched by one CU; loads
+// of label words go through agent-scope relaxed atomics (served by L2, never a stale L1 line).
+#include "kernels.hpp"
+
+namespace vf {
+
+__global__ void k_threshold_mask(const float *__restrict__ q, const uint8_t *__restrict__ roi, const float *__restrict__ thr,
+                                 uint8_t *__restrict__ out, int P)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    size_t b = blockIdx.y;
+    if (p >= P) return;
+    float v = q[b * (size_t)P + p];
+    out[b * (size_t)P + p] = (uint8_t)(roi[p] && finitef(v) && v >= thr[b]);
+}
+void launch_threshold_mask(const float *q, const uint8_t *roi, const float *thr, uint8_t *out, int B, int P, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_threshold_mask, dim3((P + 255) / 256, B), dim3(256), 0, st, q, roi, thr, out, P);
+}
+
+// ---- union-find ---------------------------------------------------------------------------------
+__device__ inline int ld_label(const int32_t *L, int i)
+{
+    return __hip_atomic_load(&L[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline int cc_find(const int32_t *L, int i)
+{
+    int p = ld_label(L, i);
+    while (p != i) { i = p; p = ld_label(L, i); }
+    return i;
+}
+__device__ inline void cc_unite(int32_t *L, int a, int b)
+{
+    for (;;) {
+        a = cc_find(L, a);
+        b = cc_find(L, b);
+        if (a == b) return;
+        if (a > b) { int t = a; a = b; b = t; }
+        // a < b: hang root b under a if b is still a root
+        int old = atomicMin(&L[b], a);
+        if (old == b) return;
+        b = old;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_cc_label(const uint8_t *__restrict__ mask, int32_t *__restrict__ labels, int h, int w)
+{
+    size_t b = blockIdx.x;
+    int P = h * w;
+    const uint8_t *m = mask + b * (size_t)P;
+    int32_t *L = labels + b * (size_t)P;
+    for (int p = threadIdx.x; p < P; p += blockDim.x) L[p] = m[p] ? p : -1;
+    __threadfence();
+    __syncthreads();
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
+        if (!m[p]) continue;
+        int y = p / w, x = p - y * w;
+        if (x > 0 && m[p - 1]) cc_unite(L, p, p - 1);
+        if (y > 0) {
+            if (m[p - w]) cc_unite(L, p, p - w);
+            if (x > 0 && m[p - w - 1]) cc_unite(L, p, p - w - 1);
+            if (x < w - 1 && m[p - w + 1]) cc_unite(L, p, p - w + 1);
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    for (int p = threadIdx.x; p < P; p += blockDim.x)
+        if (m[p]) { int r = cc_find(L, p); if (r != p) atomicMin(&L[p], r); }
+}
+
+void launch_cc_label(const uint8_t *mask, int32_t *labels, int B, int h, int w, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_cc_label, dim3(B), dim3(1024), 0, st, mask, labels, h, w);
+}
+
+// areas per root (wave-aggregated atomics), then the largest root (ties: smallest root index = first
+// in raster order = smallest OpenCV label), then out = (label == best) & and_static
+__global__ __launch_bounds__(1024) void k_cc_largest(const int32_t *__restrict__ labels, int32_t *__restrict__ area,
+                                                     const uint8_t *__restrict__ and_static, uint8_t *__restrict__ out, int P)
+{
+    __shared__ unsigned long long scratch[16];
+    size_t b = blockIdx.x;
+    const int32_t *L = labels + b * (size_t)P;
+    int32_t *A = area + b * (size_t)P;
+    int lane = threadIdx.x & 63;
+    for (int p = threadIdx.x; p < P; p += blockDim.x) A[p] = 0;
+    __threadfence();
+    __syncthreads();
+    int Pr = ((P + 1023) / 1024) * 1024;
+    for (int p = threadIdx.x; p < Pr; p += blockDim.x) {
+        int root = p < P ? L[p] : -1;
+        unsigned long long active = __ballot(root >= 0);
+        while (active) {
+            int leader = __ffsll((long long)active) - 1;
+            int r0 = __shfl(root, leader, 64);
+            unsigned long long same = __ballot(root == r0);
+            if (lane == leader) atomicAdd(&A[r0], (int)__popcll(same));
+            active &= ~same;
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    unsigned long long best = 0;
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
+        if (L[p] != p) continue;
+        int a = __hip_atomic_load(&A[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long key = ((unsigned long long)(unsigned int)a << 32) | (unsigned int)(0x7fffffff - p);
+        if (key > best) best = key;
+    }
+    best = block_max_u64(best, scratch);
+    int broot = (best >> 32) ? (0x7fffffff - (int)(best & 0xffffffffu)) : -2;
+    for (int p = threadIdx.x; p < P; p += blockDim.x)
+        out[b * (size_t)P + p] = (uint8_t)(L[p] == broot && (!and_static || and_static[p]));
+}
+
+void launch_cc_largest(const int32_t *labels, int32_t *area_scratch, unsigned long long *best, const uint8_t *and_static,
+                       uint8_t *out, int B, int P, hipStream_t st)
+{
+    (void)best;
+    hipLaunchKernelGGL(k_cc_largest, dim3(B), dim3(1024), 0, st, labels, area_scratch, and_static, out, P);
+}
+
+// ---- chamfer distance ---------------------------------------------------------------------------
+constexpr int CH_INF = 1 << 20;
+constexpr int CH_HV = 62587;    // cvRound(0.955  * 65536)
+constexpr int CH_DG = 89738;    // cvRound(1.3693 * 65536)
+constexpr int CH_DIST_MAX = 0x7fffffff >> 2;
+
+// horizontal distance to the nearest "zero" pixel of each row (one thread per row)
+__global__ void k_rowdist(const uint8_t *__restrict__ src, int invert, int32_t *__restrict__ g, int h, int w, int B)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * h) return;
+    const uint8_t *s = src + (size_t)t * w;
+    int32_t *o = g + (size_t)t * w;
+    int d = CH_INF;
+    for (int x = 0; x < w; x++) {
+        bool zero = invert ? (s[x] != 0) : (s[x] == 0);
+        d = zero ? 0 : (d >= CH_INF ? CH_INF : d + 1);
+        o[x] = d;
+    }
+    d = CH_INF;
+    for (int x = w - 1; x >= 0; x--) {
+        bool zero = invert ? (s[x] != 0) : (s[x] == 0);
+        d = zero ? 0 : (d >= CH_INF ? CH_INF : d + 1);
+        if (d < o[x]) o[x] = d;
+    }
+}
+
+// d(x,y) = min over rows y' of HV*|g-dy| + DG*min(g,dy)  (the two-pass 3x3 chamfer result, closed form)
+__global__ void k_chamfer_cols(const int32_t *__restrict__ g, float *__restrict__ dist, int h, int w, int cap)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y;
+    size_t b = blockIdx.z;
+    if (x >= w) return;
+    const int32_t *G = g + b * (size_t)h * w;
+    int best = CH_DIST_MAX;
+    for (int dy = 0; dy <= cap; dy++) {
+        if ((long long)dy * CH_HV >= best) break;
+        for (int s = 0; s < 2; s++) {
+            if (s && !dy) break;
+            int yy = s ? y + dy : y - dy;
+            if (yy < 0 || yy >= h) continue;
+            int gx = G[(size_t)yy * w + x];
+            if (gx >= CH_INF) continue;
+            int mn = gx < dy ? gx : dy, mx = gx < dy ? dy : gx;
+            int c = CH_HV * (mx - mn) + CH_DG * mn;
+            if (c < best) best = c;
+        }
+    }
+    dist[b * (size_t)h * w + (size_t)y * w + x] = (float)best * (1.0f / 65536.0f);
+}
+
+void launch_chamfer(const uint8_t *src, bool invert, int32_t *rowdist, float *dist, int B, int h, int w, int cap_px, hipStream_t st)
+{
+    int rows = B * h;
+    hipLaunchKernelGGL(k_rowdist, dim3((rows + 63) / 64), dim3(64), 0, st, src, invert ? 1 : 0, rowdist, h, w, B);
+    int cap = (int)((cap_px + 2) / 0.955) + 2;
+    if (cap > h) cap = h;
+    hipLaunchKernelGGL(k_chamfer_cols, dim3((w + 255) / 256, h, B), dim3(256), 0, st, rowdist, dist, h, w, cap);
+}
+
+__global__ void k_erode_by_dist(const float *__restrict__ dist, const uint8_t *__restrict__ src, float margin, uint8_t *__restrict__ out, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = (uint8_t)(src[i] && dist[i] > margin);
+}
+void launch_erode_by_dist(const float *dist, const uint8_t *src, float margin, uint8_t *out, int B, int P, hipStream_t st)
+{
+    size_t n = (size_t)B * P;
+    hipLaunchKernelGGL(k_erode_by_dist, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dist, src, margin, out, n);
+}
+
+}  // namespace vf

@@ -1,0 +1,343 @@
+// cv2.inpaint(img_f32, mask, radius, INPAINT_TELEA) on the GPU (shape_ftp.py:652-666, :1199).
+//
+// Telea's fast-marching inpaint is ordered by a stable priority queue keyed on (T, push sequence)
+// [OpenCV photo/inpaint.cpp CvPriorityQueueFloat], so the march itself is sequential per frame.  One
+// wavefront owns one frame: the queue lives in LDS and is popped by a 64-lane parallel arg-min, the
+// four quadrant solves of a pixel run on four lanes, and the (2r+1)^2 neighbourhood sums of Telea's
+// estimator run one neighbour per lane with wave reductions.  Frames are independent, so a batch
+// fills the chip with one wave per frame.
+//
+// Mutable per-frame state: flag planes (LDS when (h+2)*(w+2) fits, else global), T field and image in
+// global memory.  Global mutable words are read with agent-scope relaxed atomic loads (L2-served)
+// and every store is drained (workgroup fence) before the next dependent read.
+#include "kernels.hpp"
+
+namespace vf {
+
+constexpr int TQ_CAP = 4096;                 // LDS queue capacity (entries)
+constexpr uint8_t T_KNOWN = 0, T_BAND = 1, T_INSIDE = 2, T_CHANGE = 3, T_SEED = 0x80;   // T_SEED: bit flag, initial band
+
+__device__ inline float ldc(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <bool LF>
+__device__ inline uint8_t ldf(const uint8_t *f, int i)
+{
+    if (LF) return f[i];
+    return __hip_atomic_load(f + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline void drain() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+
+struct TQueue {
+    unsigned long long *key;   // (float bits of T >= 0) << 32 | seq
+    int *idx;
+    int n, cap;
+    unsigned int seq;
+    int overflow;
+};
+
+__device__ inline void tq_push(TQueue &q, float T, int idx, int lane)
+{
+    if (q.n >= q.cap) { q.overflow = 1; return; }
+    if (lane == 0) {
+        q.key[q.n] = ((unsigned long long)__float_as_uint(T) << 32) | q.seq;
+        q.idx[q.n] = idx;
+    }
+    q.n++;
+    q.seq++;
+}
+
+// pop the entry with the smallest (T, seq); returns pixel index or -1 when empty (uniform)
+__device__ inline int tq_pop(TQueue &q, int lane)
+{
+    if (q.n == 0) return -1;
+    unsigned long long best = ~0ull;
+    int bslot = -1;
+    for (int j = lane; j < q.n; j += 64) {
+        unsigned long long k = q.key[j];
+        if (k < best) { best = k; bslot = j; }
+    }
+    unsigned long long m = wave_min_u64(best);
+    unsigned long long who = __ballot(best == m && bslot >= 0);
+    int leader = __ffsll((long long)who) - 1;
+    int slot = __shfl(bslot, leader, 64);
+    int idx = q.idx[slot];
+    int last = q.n - 1;
+    if (lane == 0 && slot != last) { q.key[slot] = q.key[last]; q.idx[slot] = q.idx[last]; }
+    q.n = last;
+    return idx;
+}
+
+template <bool LF>
+__device__ inline float fmm_solve(const uint8_t *f, const float *t, int p1, int p2)
+{
+    double a11 = ldc(t + p1), a22 = ldc(t + p2);
+    double m12 = a11 < a22 ? a11 : a22;
+    bool k1 = ldf<LF>(f, p1) != T_INSIDE, k2 = ldf<LF>(f, p2) != T_INSIDE;
+    double sol;
+    if (k1) {
+        if (k2) {
+            if (fabs(a11 - a22) >= 1.0) sol = 1 + m12;
+            else sol = (a11 + a22 + sqrt((double)(2 - (a11 - a22) * (a11 - a22)))) * 0.5;
+        } else sol = 1 + a11;
+    } else if (k2) sol = 1 + a22;
+    else sol = 1 + m12;
+    return (float)sol;
+}
+
+// dist of pixel p = min over the four quadrants; lanes 0..3 each solve one quadrant
+template <bool LF>
+__device__ inline float fmm_dist(const uint8_t *f, const float *t, int p, int ec, int lane)
+{
+    int q = lane & 3;
+    int p1 = (q & 1) ? p + ec : p - ec;      // (i-1,j) (i+1,j) (i-1,j) (i+1,j)
+    int p2 = (q & 2) ? p + 1 : p - 1;        // (i,j-1) (i,j-1) (i,j+1) (i,j+1)
+    float s = fmm_solve<LF>(f, t, p1, p2);
+    float o = __shfl_xor(s, 1, 64); s = o < s ? o : s;
+    o = __shfl_xor(s, 2, 64); s = o < s ? o : s;
+    return __shfl(s, 0, 64);
+}
+
+template <bool LF>
+__global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const uint8_t *__restrict__ bad_all, int range,
+                                              uint8_t *gflags, float *gT, int32_t *status, int h, int w)
+{
+    extern __shared__ unsigned char lds_raw[];
+    const int lane = threadIdx.x;
+    const size_t b = blockIdx.x;
+    const int er = h + 2, ec = w + 2, en = er * ec, P = h * w;
+    float *img = img_all + b * (size_t)P;
+    const uint8_t *bad = bad_all + b * (size_t)P;
+    float *t = gT + b * (size_t)en;
+    TQueue q;
+    q.key = (unsigned long long *)lds_raw;
+    q.idx = (int *)(lds_raw + (size_t)TQ_CAP * 8);
+    q.cap = TQ_CAP; q.n = 0; q.seq = 0; q.overflow = 0;
+    uint8_t *f, *fo;
+    if (LF) { f = lds_raw + (size_t)TQ_CAP * 12; fo = f + ((en + 15) & ~15); }
+    else { f = gflags + b * (size_t)en * 2; fo = f + en; }
+
+    // ---- flags: f = INSIDE on the hole; band = 4-neighbour dilation minus hole; ring for the outside T field
+    int nbad = 0;
+    for (int i = lane; i < en; i += 64) {
+        int y = i / ec, x = i - y * ec;
+        bool in = (y >= 1 && y <= h && x >= 1 && x <= w) && bad[(size_t)(y - 1) * w + (x - 1)];
+        f[i] = in ? T_INSIDE : T_KNOWN;
+        t[i] = 1.0e6f;
+        nbad += in;
+    }
+    nbad = wave_sum(nbad);
+    drain();
+    __syncthreads();
+    if (nbad == 0) return;
+    for (int i = lane; i < en; i += 64) {
+        int y = i / ec, x = i - y * ec;
+        bool interior = (y >= 1 && y <= h && x >= 1 && x <= w);
+        uint8_t v = T_KNOWN;
+        if (interior && ldf<LF>(f, i) != T_INSIDE) {
+            bool near = false;
+            for (int a = -range; a <= range && !near; a++) {
+                int yy = y + a; if (yy < 0 || yy >= er) continue;
+                for (int c = -range; c <= range; c++) {
+                    int xx = x + c; if (xx < 0 || xx >= ec) continue;
+                    if (ldf<LF>(f, yy * ec + xx) == T_INSIDE) { near = true; break; }
+                }
+            }
+            bool band = ldf<LF>(f, i - 1) == T_INSIDE || ldf<LF>(f, i + 1) == T_INSIDE || ldf<LF>(f, i - ec) == T_INSIDE ||
+                        ldf<LF>(f, i + ec) == T_INSIDE;
+            if (band) { v = T_KNOWN | T_SEED; t[i] = 0.f; }   // seeds: known, T = 0 (Heap->Add(band) / Out->Add(band))
+            else if (near) v = T_INSIDE;
+        }
+        fo[i] = v;
+    }
+    drain();
+    __syncthreads();
+
+    // ---- pass 1: outside T field.  Seeds (band, T = 0) pop first, in raster order.
+    for (int phase = 0; phase < 2; phase++) {
+        int base = 0;
+        unsigned long long pend = 0;
+        for (;;) {
+            int p;
+            if (phase == 0) {
+                while (!pend && base < en) {
+                    int i = base + lane;
+                    pend = __ballot(i < en && (ldf<LF>(fo, i) & T_SEED));
+                    if (!pend) base += 64;
+                }
+                if (!pend) break;
+                int l = __ffsll((long long)pend) - 1;
+                pend &= pend - 1;
+                p = base + l;
+                if (!pend) base += 64;
+            } else {
+                p = tq_pop(q, lane);
+                if (p < 0) break;
+            }
+            if (lane == 0) fo[p] = (uint8_t)(T_CHANGE | (phase == 0 ? T_SEED : 0));
+            // the four 4-neighbours are independent of one another in this pass: lanes 0..15 = 4 pixels x 4 quadrants
+            int nb = lane >> 2;
+            int pn = nb == 0 ? p - ec : nb == 1 ? p - 1 : nb == 2 ? p + ec : p + 1;
+            bool ok = false;
+            float dist = 0.f;
+            if (lane < 16) {
+                int y = pn / ec, x = pn - y * ec;
+                ok = (y > 0 && x > 0 && y < er - 1 && x < ec - 1) && ldf<LF>(fo, pn) == T_INSIDE;
+            }
+            if (__ballot(ok)) {
+                drain();
+                if (ok) {
+                    int qd = lane & 3;
+                    int p1 = (qd & 1) ? pn + ec : pn - ec;
+                    int p2 = (qd & 2) ? pn + 1 : pn - 1;
+                    dist = fmm_solve<LF>(fo, t, p1, p2);
+                }
+                float o = __shfl_xor(dist, 1, 64); dist = o < dist ? o : dist;
+                o = __shfl_xor(dist, 2, 64); dist = o < dist ? o : dist;
+                for (int k = 0; k < 4; k++) {
+                    bool okk = __shfl((int)ok, k * 4, 64) != 0;
+                    if (!okk) continue;
+                    float dk = __shfl(dist, k * 4, 64);
+                    int pk = __shfl(pn, k * 4, 64);
+                    if (lane == 0) { t[pk] = dk; fo[pk] = T_BAND; }
+                    tq_push(q, dk, pk, lane);
+                }
+            }
+            if (LF) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        }
+    }
+    drain();
+    __syncthreads();
+    // negate T where the outside pass ran (CHANGE), seeds keep T = 0
+    for (int i = lane; i < en; i += 64)
+        if ((ldf<LF>(fo, i) & 0x7f) == T_CHANGE) { float v = ldc(t + i); t[i] = -v; }
+    drain();
+    __syncthreads();
+
+    // ---- pass 2: Telea march.  Seeds = band pixels (raster order), then the queue.
+    q.n = 0; q.seq = 0;
+    const int r2 = range * range;
+    const int side = 2 * range + 1, nn = side * side;
+    for (int phase = 0; phase < 2; phase++) {
+        int base = 0;
+        unsigned long long pend = 0;
+        for (;;) {
+            int p;
+            if (phase == 0) {
+                while (!pend && base < en) {
+                    int i = base + lane;
+                    pend = __ballot(i < en && (ldf<LF>(fo, i) & T_SEED));
+                    if (!pend) base += 64;
+                }
+                if (!pend) break;
+                int l = __ffsll((long long)pend) - 1;
+                pend &= pend - 1;
+                p = base + l;
+                if (!pend) base += 64;
+            } else {
+                p = tq_pop(q, lane);
+                if (p < 0) break;
+            }
+            if (phase == 1 && lane == 0) f[p] = T_KNOWN;
+            if (LF) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); else drain();
+            for (int qn = 0; qn < 4; qn++) {
+                int pi = qn == 0 ? p - ec : qn == 1 ? p - 1 : qn == 2 ? p + ec : p + 1;
+                int i = pi / ec, j = pi - i * ec;
+                if (i <= 0 || j <= 0 || i >= er - 1 || j >= ec - 1) continue;
+                if (ldf<LF>(f, pi) != T_INSIDE) continue;
+                drain();
+                float dist = fmm_dist<LF>(f, t, pi, ec, lane);
+                if (lane == 0) t[pi] = dist;
+                // gradT at (i,j): uses the T just computed for the centre
+                float tc = dist;
+                float gtx, gty;
+                {
+                    bool kr = ldf<LF>(f, pi + 1) != T_INSIDE, kl = ldf<LF>(f, pi - 1) != T_INSIDE;
+                    float tr = ldc(t + pi + 1), tl = ldc(t + pi - 1);
+                    if (kr) gtx = kl ? __fmul_rn(__fsub_rn(tr, tl), 0.5f) : __fsub_rn(tr, tc);
+                    else gtx = kl ? __fsub_rn(tc, tl) : 0.f;
+                    bool kd = ldf<LF>(f, pi + ec) != T_INSIDE, ku = ldf<LF>(f, pi - ec) != T_INSIDE;
+                    float td = ldc(t + pi + ec), tu = ldc(t + pi - ec);
+                    if (kd) gty = ku ? __fmul_rn(__fsub_rn(td, tu), 0.5f) : __fsub_rn(td, tc);
+                    else gty = ku ? __fsub_rn(tc, tu) : 0.f;
+                }
+                double sIa = 0, sJx = 0, sJy = 0, sS = 0;
+                for (int n0 = 0; n0 < nn; n0 += 64) {
+                    int nidx = n0 + lane;
+                    float cIa = 0.f, cJx = 0.f, cJy = 0.f, cS = 0.f;
+                    if (nidx < nn) {
+                        int k = i - range + nidx / side, l = j - range + nidx % side;
+                        if (k > 0 && l > 0 && k < er - 1 && l < ec - 1) {
+                            int pk = k * ec + l;
+                            if (ldf<LF>(f, pk) != T_INSIDE && ((l - j) * (l - j) + (k - i) * (k - i) <= r2)) {
+                                int km = k - 1 + (k == 1), kp = k - 1 - (k == er - 2);
+                                int lm = l - 1 + (l == 1), lp = l - 1 - (l == ec - 2);
+                                float ry = (float)(i - k), rx = (float)(j - l);
+                                float len2 = __fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry));
+                                float dstw = (float)(1. / (double)__fmul_rn(len2, __fsqrt_rn(len2)));
+                                float tk = (pk == pi) ? tc : ldc(t + pk);
+                                float lev = (float)(1. / (1 + fabs((double)__fsub_rn(tk, tc))));
+                                float dir = __fadd_rn(__fmul_rn(rx, gtx), __fmul_rn(ry, gty));
+                                if (fabs((double)dir) <= 0.01) dir = 0.000001f;
+                                float wgt = fabsf(__fmul_rn(__fmul_rn(dstw, lev), dir));
+                                float gix, giy;
+                                bool kr = ldf<LF>(f, pk + 1) != T_INSIDE, kl = ldf<LF>(f, pk - 1) != T_INSIDE;
+                                if (kr) gix = kl ? __fmul_rn(__fsub_rn(ldc(img + (size_t)km * w + lp + 1), ldc(img + (size_t)km * w + lm - 1)), 2.0f)
+                                                 : __fsub_rn(ldc(img + (size_t)km * w + lp + 1), ldc(img + (size_t)km * w + lm));
+                                else gix = kl ? __fsub_rn(ldc(img + (size_t)km * w + lp), ldc(img + (size_t)km * w + lm - 1)) : 0.f;
+                                bool kd = ldf<LF>(f, pk + ec) != T_INSIDE, ku = ldf<LF>(f, pk - ec) != T_INSIDE;
+                                if (kd) giy = ku ? __fmul_rn(__fsub_rn(ldc(img + (size_t)(kp + 1) * w + lm), ldc(img + (size_t)(km - 1) * w + lm)), 2.0f)
+                                                 : __fsub_rn(ldc(img + (size_t)(kp + 1) * w + lm), ldc(img + (size_t)km * w + lm));
+                                else giy = ku ? __fsub_rn(ldc(img + (size_t)kp * w + lm), ldc(img + (size_t)(km - 1) * w + lm)) : 0.f;
+                                cIa = __fmul_rn(wgt, ldc(img + (size_t)km * w + lm));
+                                cJx = __fmul_rn(wgt, __fmul_rn(gix, rx));
+                                cJy = __fmul_rn(wgt, __fmul_rn(giy, ry));
+                                cS = wgt;
+                            }
+                        }
+                    }
+                    sIa += wave_sum((double)cIa);
+                    sJx -= wave_sum((double)cJx);
+                    sJy -= wave_sum((double)cJy);
+                    sS += wave_sum((double)cS);
+                }
+                float Ia = (float)sIa, Jx = (float)sJx, Jy = (float)sJy, s = (float)(sS + 1.0e-20);
+                float val = (float)((double)__fdiv_rn(Ia, s) +
+                                    (double)__fadd_rn(Jx, Jy) / (sqrt((double)__fadd_rn(__fmul_rn(Jx, Jx), __fmul_rn(Jy, Jy))) + (double)1.0e-20f));
+                if (lane == 0) { img[(size_t)(i - 1) * w + (j - 1)] = val; f[pi] = T_BAND; }
+                tq_push(q, dist, pi, lane);
+                if (LF) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            }
+        }
+    }
+    if (q.overflow && lane == 0) status[b] = 2;
+}
+
+size_t inpaint_scratch_bytes_per_frame(int h, int w)
+{
+    size_t en = (size_t)(h + 2) * (w + 2);
+    return en * sizeof(float) + 2 * en + 64;
+}
+
+static size_t telea_lds_bytes(int h, int w)
+{
+    size_t en = (size_t)(h + 2) * (w + 2);
+    return (size_t)TQ_CAP * 12 + 2 * ((en + 15) & ~(size_t)15);
+}
+
+void launch_inpaint_telea(float *img, const uint8_t *bad, int range, void *scratch, int32_t *status, int B, int h, int w,
+                          hipStream_t st)
+{
+    size_t en = (size_t)(h + 2) * (w + 2);
+    // scratch layout: [B*en floats T][B*2*en bytes flags]
+    float *gT = (float *)scratch;
+    uint8_t *gflags = (uint8_t *)scratch + (size_t)B * en * sizeof(float);
+    size_t lds_full = telea_lds_bytes(h, w);
+    if (lds_full <= 160 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) { hipFuncSetAttribute((const void *)k_telea<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        hipLaunchKernelGGL(k_telea<true>, dim3(B), dim3(64), lds_full, st, img, bad, range, gflags, gT, status, h, w);
+    } else {
+        hipLaunchKernelGGL(k_telea<false>, dim3(B), dim3(64), (size_t)TQ_CAP * 12, st, img, bad, range, gflags, gT, status, h, w);
+    }
+}
+
+}  // namespace vf

@@ -1,0 +1,215 @@
+// unwrap_quality_guided on the GPU (shape_ftp.py:1043-1080).
+//
+// The reference grows a region from the best-quality pixel with a max-heap of tuples
+// (-q, y, x, py, px).  That is Prim-style growth with a total order: the next pixel is the frontier
+// pixel with the largest (q, then smallest (y, x)), and its parent is the lexicographically smallest
+// (py, px) among its neighbours visited so far.  The growth order is inherently sequential, so:
+//   k_unwrap_flood  one wavefront per frame replays exactly that order (frontier keys in LDS, 64-lane
+//                   arg-max per step, the 8 neighbours examined by 8 lanes) and records only the
+//                   spanning tree (parent index per pixel);
+//   k_unwrap_inc / k_unwrap_jump / k_unwrap_apply  (parallel) turn the tree into integer wrap counts
+//                   by pointer jumping (integer sums are associative, so any evaluation order gives
+//                   the tree's exact counts) and write u = w + 2*pi*k.
+// In exact arithmetic u[p] - w[p] is the same multiple of 2*pi as in the reference's
+// u[p] = u[parent] + angle(exp(1j*(w[p]-w[parent]))) chain; only float32 rounding along the chain differs.
+#include "kernels.hpp"
+
+namespace vf {
+
+__device__ inline uint8_t ld_st(const uint8_t *st, int i, bool lds)
+{
+    if (lds) return st[i];
+    return __hip_atomic_load(st + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool LS>
+__global__ __launch_bounds__(64) void k_unwrap_flood(const float *__restrict__ quality_all, const uint8_t *__restrict__ mask_all,
+                                                     int32_t *__restrict__ parent_all, uint8_t *gst, uint32_t *gfq, uint32_t *gfi,
+                                                     int cap, int32_t *status, int h, int w)
+{
+    extern __shared__ unsigned char lds_raw[];
+    const int lane = threadIdx.x;
+    const size_t b = blockIdx.x;
+    const int P = h * w;
+    const float *quality = quality_all + b * (size_t)P;
+    const uint8_t *mask = mask_all + b * (size_t)P;
+    int32_t *parent = parent_all + b * (size_t)P;
+    uint32_t *fq, *fi;
+    uint8_t *st;
+    if (LS) { fq = (uint32_t *)lds_raw; fi = fq + cap; st = (uint8_t *)(fi + cap); }
+    else { fq = gfq + b * (size_t)cap; fi = gfi + b * (size_t)cap; st = gst + b * (size_t)P; }
+
+    // st: 0 untouched, 1 in frontier, 2 visited.  Seed = first arg-max of q over the mask.
+    unsigned long long best = 0;
+    for (int p = lane; p < P; p += 64) {
+        st[p] = 0;
+        parent[p] = -1;
+        if (mask[p]) {
+            unsigned long long k = ((unsigned long long)f2key(quality[p]) << 32) | (uint32_t)(0xffffffffu - (uint32_t)p);
+            if (k > best) best = k;
+        }
+    }
+    best = wave_max_u64(best);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __syncthreads();
+    if (best == 0) return;   // empty mask: everything stays NaN (shape_ftp.py:1047-1048)
+    int F = 0;
+    bool overflow = false;
+    int cur = (int)(0xffffffffu - (uint32_t)(best & 0xffffffffu));
+    bool is_seed = true;
+
+    for (;;) {
+        // ---- visit `cur`: parent = lexicographically smallest visited neighbour; push new neighbours
+        int y = cur / w, x = cur - y * w;
+        int np = -1;
+        uint8_t s = 255;
+        if (lane < 8) {
+            int l = lane < 4 ? lane : lane + 1;          // skip the centre of the 3x3
+            int ny = y + l / 3 - 1, nx = x + l % 3 - 1;
+            if (ny >= 0 && ny < h && nx >= 0 && nx < w) { np = ny * w + nx; s = ld_st(st, np, LS); }
+        }
+        unsigned long long vis = __ballot(s == 2);
+        int par = cur;
+        if (!is_seed) {
+            int pl = __ffsll((long long)vis) - 1;      // always >= 0: cur entered the frontier from a visited pixel
+            par = __shfl(np, pl, 64);
+        }
+        bool fresh = (s == 0) && mask[np < 0 ? 0 : np] && np >= 0;
+        uint32_t nk = fresh ? f2key(quality[np]) : 0u;
+        unsigned long long nb = __ballot(fresh);
+        int cnt = (int)__popcll(nb);
+        if (F + cnt > cap) { overflow = true; break; }
+        if (fresh) {
+            int pos = F + (int)__popcll(nb & ((1ull << lane) - 1ull));
+            fq[pos] = nk;
+            fi[pos] = (uint32_t)np;
+            st[np] = 1;
+        }
+        if (lane == 0) { parent[cur] = par; st[cur] = 2; }
+        F += cnt;
+        is_seed = false;
+        if (F == 0) break;
+        if (!LS) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+
+        // ---- pop the frontier maximum: (q desc, index asc)
+        uint32_t bq = 0, bi = 0xffffffffu;
+        int bslot = -1;
+        for (int j = lane; j < F; j += 64) {
+            uint32_t kq = fq[j], ki = fi[j];
+            if (kq > bq || (kq == bq && ki < bi)) { bq = kq; bi = ki; bslot = j; }
+        }
+        uint32_t mq = wave_max_u32(bq);
+        unsigned long long tie = __ballot(bq == mq && bslot >= 0);
+        int leader;
+        if (__popcll(tie) == 1) leader = __ffsll((long long)tie) - 1;
+        else {
+            uint32_t mi = ~wave_max_u32((bq == mq && bslot >= 0) ? ~bi : 0u);
+            unsigned long long who = __ballot(bq == mq && bslot >= 0 && bi == mi);
+            leader = __ffsll((long long)who) - 1;
+        }
+        int slot = __shfl(bslot, leader, 64);
+        cur = (int)__shfl(bi, leader, 64);
+        int last = F - 1;
+        if (lane == 0 && slot != last) { fq[slot] = fq[last]; fi[slot] = fi[last]; }
+        F = last;
+        if (!LS) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
+    if (overflow && lane == 0) status[b] = 2;
+}
+
+// Tree -> wrap counts -> unwrapped phase, one 1024-thread workgroup per frame.
+// inc[p] = the integer n with (w[p]-w[par]) + 2*pi*n in (-pi, pi]; pointer jumping doubles the hop
+// length each round ((par, inc) -> (par[par], inc + inc[par])) until every pixel points at the seed.
+// Words written by other threads of the workgroup are read with agent-scope relaxed atomic loads.
+__device__ inline int ld_i32(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(1024) void k_unwrap_tree(const float *__restrict__ wrapped_all, int32_t *parent_all, int32_t *incA_all,
+                                                      int32_t *parB_all, int32_t *incB_all, float *__restrict__ unwrapped_all, int P)
+{
+    __shared__ int s_changed;
+    const size_t b = blockIdx.x;
+    const float *wrapped = wrapped_all + b * (size_t)P;
+    int32_t *pi = parent_all + b * (size_t)P, *ii = incA_all + b * (size_t)P;
+    int32_t *po = parB_all + b * (size_t)P, *io = incB_all + b * (size_t)P;
+    const double twopi = 6.283185307179586476925286766559, pi_d = 3.14159265358979323846;
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
+        int par = pi[p];
+        int v = 0;
+        if (par >= 0 && par != p) {
+            double d = (double)wrapped[p] - (double)wrapped[par];
+            double k = -rint(d / twopi);
+            double dd = d + twopi * k;
+            if (dd <= -pi_d) k += 1.0;
+            else if (dd > pi_d) k -= 1.0;
+            v = (int)k;
+        }
+        ii[p] = v;
+    }
+    __threadfence();
+    __syncthreads();
+    for (int round = 0; round < 40; round++) {
+        if (threadIdx.x == 0) s_changed = 0;
+        __syncthreads();
+        int changed = 0;
+        for (int p = threadIdx.x; p < P; p += blockDim.x) {
+            int par = ld_i32(pi + p);
+            int v = ld_i32(ii + p);
+            if (par >= 0) {
+                int pp = ld_i32(pi + par);
+                if (pp != par) { v += ld_i32(ii + par); par = pp; changed = 1; }
+            }
+            po[p] = par;
+            io[p] = v;
+        }
+        if (changed) s_changed = 1;
+        __threadfence();
+        __syncthreads();
+        int32_t *t = pi; pi = po; po = t;
+        t = ii; ii = io; io = t;
+        int any = s_changed;
+        __syncthreads();
+        if (!any) break;
+    }
+    float *unwrapped = unwrapped_all + b * (size_t)P;
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
+        float u = __uint_as_float(0x7fc00000u);
+        if (ld_i32(pi + p) >= 0) u = (float)((double)wrapped[p] + twopi * (double)ld_i32(ii + p));
+        unwrapped[p] = u;
+    }
+}
+
+size_t unwrap_scratch_bytes_per_frame(int h, int w)
+{
+    size_t P = (size_t)h * w;
+    return P /*st*/ + 3 * P * sizeof(uint32_t) /*frontier keys+idx, reused as jump buffers*/ + 256;
+}
+
+static int unwrap_lds_cap(int P)
+{
+    long avail = 160 * 1024 - (long)((P + 15) & ~15);
+    if (avail < 64 * 1024) return 0;
+    return (int)((avail / 8) & ~63);
+}
+
+void launch_unwrap(const float *wrapped, const float *quality, const uint8_t *mask, float *unwrapped, int32_t *parent,
+                   void *scratch, int32_t *status, int B, int h, int w, hipStream_t st)
+{
+    int P = h * w;
+    size_t n = (size_t)B * P;
+    // scratch: [B*P st bytes][B*P u32][B*P u32][B*P u32]
+    uint8_t *gst = (uint8_t *)scratch;
+    uint32_t *g0 = (uint32_t *)((uint8_t *)scratch + ((n + 255) & ~(size_t)255));
+    uint32_t *g1 = g0 + n, *g2 = g1 + n;
+    int cap = unwrap_lds_cap(P);
+    if (cap > 0) {
+        static bool attr_set = false;
+        if (!attr_set) { hipFuncSetAttribute((const void *)k_unwrap_flood<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        size_t lds = (size_t)cap * 8 + ((P + 15) & ~15);
+        hipLaunchKernelGGL(k_unwrap_flood<true>, dim3(B), dim3(64), lds, st, quality, mask, parent, gst, g0, g1, cap, status, h, w);
+    } else {
+        hipLaunchKernelGGL(k_unwrap_flood<false>, dim3(B), dim3(64), 0, st, quality, mask, parent, gst, g0, g1, P, status, h, w);
+    }
+    hipLaunchKernelGGL(k_unwrap_tree, dim3(B), dim3(1024), 0, st, wrapped, parent, (int32_t *)g0, (int32_t *)g1, (int32_t *)g2, unwrapped, P);
+}
+
+}  // namespace vf

@@ -1,0 +1,100 @@
+// Launcher declarations for the gfx950 FTP kernels.  All pointers are device pointers; planes are
+// [B, P] (P = h*w) unless noted; `st` is the HIP stream every launch goes to.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "common.hpp"
+
+namespace vf {
+
+struct RowSpanSE {      // structuring element as per-row x spans (cv::getStructuringElement ELLIPSE)
+    int k;              // k x k, anchor at centre (k <= 33)
+    int8_t lo[33];      // relative x offset of first set element in row i (lo > hi: empty row)
+    int8_t hi[33];
+};
+
+// ---- k_basic.hip ------------------------------------------------------------------------------
+void launch_to_gray(const void *frames, int format, float *gray, int B, int P, hipStream_t st);
+void launch_sobel_mag(const float *img, float *grad, int B, int h, int w, hipStream_t st);
+void launch_bad_flags(const float *img, const float *grad, const uint8_t *valid, const float *thr_hi, const float *thr_g,
+                      uint8_t *bad, int B, int P, hipStream_t st);
+void launch_morph(const uint8_t *src, uint8_t *dst, int B, int h, int w, const RowSpanSE &se, bool dilate,
+                  const uint8_t *and_static, const uint8_t *and_frame, hipStream_t st);
+void launch_gauss_rows(const float *src, float *dst, const float *kern, int ksize, int B, int h, int w, hipStream_t st);
+void launch_gauss_cols(const float *src, float *dst, const float *kern, int ksize, int B, int h, int w, hipStream_t st);
+void launch_illum_norm(const float *img, const float *blur, float *out, int B, int P, hipStream_t st);
+void launch_mul_static(const float *a, const float *stat, float *out, int B, int P, hipStream_t st);
+void launch_count_u8(const uint8_t *m, int *counts, int B, int P, hipStream_t st);
+
+// ---- k_select.hip -----------------------------------------------------------------------------
+// Per frame: values vals[b*P+i] (|.| if use_abs) over pixels with mask != 0 (mask_stride 0: one static
+// mask for all frames), finite, and (le_thr ? value <= le_thr[b] : true).
+// reqs[j] >= 0: percentile with q32 = reqs[j];  reqs[j] < 0: median.   out[b*nreq+j], counts[b].
+void launch_select(const float *vals, const uint8_t *mask, size_t mask_stride, const float *le_thr, bool use_abs,
+                   const float *reqs_dev, int nreq, float *out, int *counts, int B, int P, hipStream_t st);
+
+// ---- k_dft.hip --------------------------------------------------------------------------------
+void launch_dft_forward(const float *iw, const float *mu, const float2 *Ex, const float2 *Ey, const float *win,
+                        float2 *tmpT, float2 *patch, int B, int h, int w, int ph, int pw, hipStream_t st);
+void launch_dft_inverse(const float2 *patch, const float2 *Gx, const float2 *Gy, float2 *tmpQ, float2 *field, float *amp,
+                        int B, int h, int w, int ph, int pw, hipStream_t st);
+void launch_dft_full_mag(const float *iw, const float *mu, const float2 *Ex_full, const float2 *Ey_full, float2 *tmp,
+                         float *mag, int h, int w, int Hf, int Wf, int dc_excl, hipStream_t st);
+void launch_top_peaks(const float *mag, int Hf, int Wf, int dc, int npeaks, float *out_xyv, hipStream_t st);
+void launch_phase_diff(const float2 *cdef, const float2 *cref, const float *amp_def, const float *amp_ref, float *prod,
+                       float *wrapped, int B, int P, hipStream_t st);
+
+// ---- k_cc_dist.hip ----------------------------------------------------------------------------
+void launch_threshold_mask(const float *q, const uint8_t *roi, const float *thr, uint8_t *out, int B, int P, hipStream_t st);
+void launch_cc_label(const uint8_t *mask, int32_t *labels, int B, int h, int w, hipStream_t st);
+void launch_cc_largest(const int32_t *labels, int32_t *area_scratch, unsigned long long *best, const uint8_t *and_static,
+                       uint8_t *out, int B, int P, hipStream_t st);
+void launch_chamfer(const uint8_t *src, bool invert, int32_t *rowdist, float *dist, int B, int h, int w, int cap_px, hipStream_t st);
+void launch_erode_by_dist(const float *dist, const uint8_t *src, float margin, uint8_t *out, int B, int P, hipStream_t st);
+
+// ---- k_inpaint.hip ----------------------------------------------------------------------------
+size_t inpaint_scratch_bytes_per_frame(int h, int w);
+void launch_inpaint_telea(float *img, const uint8_t *bad, int range, void *scratch, int32_t *status, int B, int h, int w,
+                          hipStream_t st);
+
+// ---- k_unwrap.hip -----------------------------------------------------------------------------
+size_t unwrap_scratch_bytes_per_frame(int h, int w);
+void launch_unwrap(const float *wrapped, const float *quality, const uint8_t *mask, float *unwrapped, int32_t *parent,
+                   void *scratch, int32_t *status, int B, int h, int w, hipStream_t st);
+
+// ---- k_fit.hip --------------------------------------------------------------------------------
+void launch_robust_polyfit(const float *z, const uint8_t *mask, int order, int iters, float c, int min_count, float *coef_out,
+                           float *resid_out, int B, int h, int w, hipStream_t st);
+
+// ---- k_post.hip -------------------------------------------------------------------------------
+struct PostParams {
+    double mm_per_px, depth_eps_mm, period_px;
+    Curve force_curve;
+};
+void launch_contact_mask(const float *res, const uint8_t *reliable, const float *thr3, const int *rel_count, int *contact_count,
+                         float min_frac, float max_frac, uint8_t *contact, float *thr_used, int B, int P, hipStream_t st);
+void launch_background(const uint8_t *reliable, const uint8_t *contact_d, const int *rel_count, int *bg_count, uint8_t *background,
+                       int B, int P, hipStream_t st);
+void launch_sub_scalar_mask(const float *src, const float *scalar, const uint8_t *mask, float *z0, float *m_out, int B, int P,
+                            hipStream_t st);
+void launch_div_planes(const float *num, const float *den, float *out, int B, int P, hipStream_t st);
+void launch_core_flip(float *hmap, const float *core_med, int *flipped, int B, int P, hipStream_t st);
+void launch_frontier_compose(const float *hmap, const uint8_t *reliable, const uint8_t *roi, const float *dist_in, float band,
+                             float *hfinal_z0, int32_t *status, int B, int P, hipStream_t st);
+void launch_finalize_unitless(const float *hfinal_z0, const float *smooth_num, const float *roi_den, const uint8_t *reliable,
+                              const uint8_t *roi, const float *dist_out, float band, int use_band, float *unitless, int B, int P,
+                              hipStream_t st);
+void launch_to_mm(const float *unitless, const uint8_t *roi, Curve curve, int use_neg, float *depth, uint8_t *cand,
+                  unsigned int *gmax_bits, int B, int P, hipStream_t st);
+void launch_blob_filter(float *depth, const uint8_t *cand, const int32_t *labels, unsigned int *peak_bits,
+                        const unsigned int *gmax_bits, float min_peak_mm, double rel_frac, uint8_t *kept, int B, int P,
+                        hipStream_t st);
+void launch_tail(const float *height_mm, const uint8_t *roi_or_null, const float *unitless_or_null, const uint8_t *roi_static,
+                 PostParams pp, double *scalars, int nscal, double *out3_or_null, int B, int P, hipStream_t st);
+void launch_fill_scalars(double *scalars, int nscal, const int *rel_count, const int *flipped, const float *amp_thr,
+                         const float *contact_thr, const float *bg_med, const int *bad_count, int B, hipStream_t st);
+void launch_mark_empty(const int *rel_count, int32_t *status, int B, hipStream_t st);
+void launch_copy_out(const float *depth, const uint8_t *reliable, const int32_t *status, float *out_h, uint8_t *out_r, int B, int P,
+                     hipStream_t st);
+
+}  // namespace vf

@@ -1,0 +1,183 @@
+// Exact order statistics per frame (one 1024-thread workgroup per frame).
+//
+// Replaces np.percentile / np.nanpercentile / np.median / np.nanmedian on the masked, finite values
+// of a plane (shape_ftp.py:343-354, :618-622, :1124-1125).  The two neighbouring order statistics
+// are found EXACTLY (range-adaptive 2048-bucket histogram refinement over order-preserving uint32
+// keys, then rank-by-counting of <=1024 candidates in LDS); the interpolation then follows NumPy
+// 2.x's float32 arithmetic (numpy/lib/_function_base_impl.py `_quantile`, `_lerp`) so thresholds
+// equal the CPU path's to the last bit whenever the inputs do.
+#pragma once
+#include "common.hpp"
+
+namespace vf {
+
+constexpr int SEL_T = 1024;
+constexpr int SEL_NB = 2048;
+constexpr int SEL_CAND = 1024;
+
+struct SelShared {
+    uint32_t hist[SEL_NB];
+    uint32_t cand[SEL_CAND];
+    unsigned long long red64[16];
+    uint32_t wsum[16];
+    uint32_t s_bucket, s_before, s_cnt, s_ncand, s_a, s_b, s_found;
+};
+
+// Finds keys of rank k and k+1 (ascending, 0-based) among the n valid elements.
+// get(i, key) -> bool valid.  n must be > 0 and k < n.  Result in all threads.
+template <class F>
+__device__ inline void block_select2(F get, int P, uint32_t n, uint32_t k, SelShared &sh, uint32_t kmin, uint32_t kmax,
+                                     uint32_t &key_a, uint32_t &key_b)
+{
+    const int tid = threadIdx.x;
+    uint32_t lo = kmin, hi = kmax, below = 0;
+    uint32_t a = 0, b = 0;
+    for (;;) {
+        uint32_t range = hi - lo;
+        if (range == 0) { a = lo; break; }
+        int bits = 32 - __clz(range);
+        int shift = bits > 11 ? bits - 11 : 0;
+        for (int i = tid; i < SEL_NB; i += SEL_T) sh.hist[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < P; i += SEL_T) {
+            uint32_t key;
+            if (get(i, key) && key >= lo && key <= hi) atomicAdd(&sh.hist[(key - lo) >> shift], 1u);
+        }
+        __syncthreads();
+        // locate the bucket holding rank (k - below): each thread owns 2 buckets
+        uint32_t want = k - below;
+        uint32_t c0 = sh.hist[2 * tid], c1 = sh.hist[2 * tid + 1];
+        uint32_t mine = c0 + c1;
+        // exclusive prefix over threads: wave scan + wave totals
+        uint32_t incl = mine;
+        int lane = tid & 63, wid = tid >> 6;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) sh.wsum[wid] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (int i = 0; i < wid; i++) wbase += sh.wsum[i];
+        uint32_t excl = wbase + incl - mine;
+        if (want >= excl && want < excl + mine) {
+            if (want < excl + c0) { sh.s_bucket = 2 * tid; sh.s_before = excl; sh.s_cnt = c0; }
+            else { sh.s_bucket = 2 * tid + 1; sh.s_before = excl + c0; sh.s_cnt = c1; }
+        }
+        __syncthreads();
+        uint32_t bsel = sh.s_bucket, cnt = sh.s_cnt;
+        below += sh.s_before;
+        uint32_t nlo = lo + (bsel << shift);
+        uint32_t nhi = shift ? nlo + ((1u << shift) - 1u) : nlo;
+        if (nhi > hi || nhi < nlo) nhi = hi;
+        lo = nlo; hi = nhi;
+        __syncthreads();
+        if (shift == 0) { a = lo; break; }
+        if (cnt <= SEL_CAND) {
+            // collect candidates of this bucket, rank by counting
+            if (tid == 0) sh.s_ncand = 0;
+            __syncthreads();
+            for (int i = tid; i < P; i += SEL_T) {
+                uint32_t key;
+                if (get(i, key) && key >= lo && key <= hi) { uint32_t pos = atomicAdd(&sh.s_ncand, 1u); if (pos < SEL_CAND) sh.cand[pos] = key; }
+            }
+            __syncthreads();
+            uint32_t m = sh.s_ncand;
+            uint32_t want2 = k - below;
+            if (tid == 0) { sh.s_found = 0; }
+            __syncthreads();
+            if ((uint32_t)tid < m) {
+                uint32_t c = sh.cand[tid], r = 0;
+                for (uint32_t j = 0; j < m; j++) { uint32_t o = sh.cand[j]; r += (o < c) || (o == c && j < (uint32_t)tid); }
+                if (r == want2) sh.s_a = c;
+                if (r == want2 + 1) { sh.s_b = c; sh.s_found = 1; }
+            }
+            __syncthreads();
+            a = sh.s_a;
+            if (sh.s_found) { key_a = a; key_b = sh.s_b; __syncthreads(); return; }
+            break;
+        }
+    }
+    // b = next order statistic: a again if duplicated, else the smallest key above a
+    {
+        uint32_t le = 0;
+        unsigned long long nxt = ~0ull;
+        for (int i = tid; i < P; i += SEL_T) {
+            uint32_t key;
+            if (get(i, key)) { le += key <= a; if (key > a && (unsigned long long)key < nxt) nxt = key; }
+        }
+        __syncthreads();
+        uint32_t tot = block_sum<uint32_t>(le, sh.wsum);
+        unsigned long long mn = block_min_u64(nxt, sh.red64);
+        b = (k + 1 < tot || mn == ~0ull) ? a : (uint32_t)mn;
+        __syncthreads();
+    }
+    key_a = a; key_b = b;
+}
+
+// count / min / max of valid keys
+template <class F>
+__device__ inline void block_minmax(F get, int P, SelShared &sh, uint32_t &n, uint32_t &kmin, uint32_t &kmax)
+{
+    uint32_t c = 0;
+    unsigned long long mn = ~0ull, mx = 0;
+    for (int i = threadIdx.x; i < P; i += SEL_T) {
+        uint32_t key;
+        if (get(i, key)) { c++; if (key < mn) mn = key; if (key + 1ull > mx) mx = key + 1ull; }
+    }
+    __syncthreads();
+    n = block_sum<uint32_t>(c, sh.wsum);
+    mn = block_min_u64(mn, sh.red64);
+    mx = block_max_u64(mx, sh.red64);
+    kmin = (uint32_t)mn; kmax = mx ? (uint32_t)(mx - 1) : 0;
+    __syncthreads();
+}
+
+// NumPy 2.x percentile (method 'linear') of float32 data, float32 arithmetic:
+//   vi = n*q + (1 + q*(-1)) - 1 ; prev = floor(vi) ; gamma = vi - prev
+//   res = a + (b-a)*gamma  [ b - (b-a)*(1-gamma) when gamma >= 0.5 ]
+__device__ inline void np_percentile_index(uint32_t n, float q32, uint32_t &k, float &gamma, bool &top)
+{
+    float vi = __fsub_rn(__fadd_rn(__fmul_rn((float)n, q32), __fadd_rn(1.0f, __fmul_rn(q32, -1.0f))), 1.0f);
+    top = vi >= (float)(n - 1);
+    if (vi < 0.0f) { k = 0; gamma = 0.0f; return; }
+    float pf = floorf(vi);
+    k = (uint32_t)pf;
+    gamma = __fsub_rn(vi, pf);
+    if (top) { k = n - 1; gamma = 0.0f; }
+}
+__device__ inline float np_lerp(float a, float b, float t)
+{
+    float d = __fsub_rn(b, a);
+    float r = __fadd_rn(a, __fmul_rn(d, t));
+    if (t >= 0.5f) r = __fsub_rn(b, __fmul_rn(d, __fsub_rn(1.0f, t)));
+    return r;
+}
+
+// percentile (q32 = float32(q)/float32(100)) of valid elements; NaN when n == 0
+template <class F>
+__device__ inline float block_percentile(F get, int P, float q32, SelShared &sh, uint32_t n, uint32_t kmin, uint32_t kmax)
+{
+    if (n == 0) return __uint_as_float(0x7fc00000u);
+    uint32_t k; float g; bool top;
+    np_percentile_index(n, q32, k, g, top);
+    uint32_t ka, kb;
+    if (k + 1 >= n) {  // last element: both neighbours are the maximum
+        if (k >= n) k = n - 1;
+        return key2f(kmax);
+    }
+    block_select2(get, P, n, k, sh, kmin, kmax, ka, kb);
+    return np_lerp(key2f(ka), key2f(kb), g);
+}
+
+// np.median of valid elements (mean of the two middle values in float32 for even n)
+template <class F>
+__device__ inline float block_median(F get, int P, SelShared &sh, uint32_t n, uint32_t kmin, uint32_t kmax)
+{
+    if (n == 0) return __uint_as_float(0x7fc00000u);
+    if (n == 1) return key2f(kmin);
+    uint32_t ka, kb;
+    if (n & 1u) { block_select2(get, P, n, (n - 1) / 2, sh, kmin, kmax, ka, kb); return key2f(ka); }
+    block_select2(get, P, n, n / 2 - 1, sh, kmin, kmax, ka, kb);
+    return __fdiv_rn(__fadd_rn(key2f(ka), key2f(kb)), 2.0f);
+}
+
+}  // namespace vf
