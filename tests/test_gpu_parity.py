@@ -1,0 +1,254 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+
+Tolerances (BASELINE.json north_star): height maps within 1e-4 relative to the map's peak value
+(`|gpu - oracle| <= 1e-4 * max|oracle|`, float32 path), scalars within 1e-4 relative, the
+arg-extremum ("contact-location") index bit-exact, byte masks equal.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ftp_oracle as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def cal(pkg):
+    model, neg = pkg.load_calibration(os.path.join(G, "calibration_phase_to_height.json"))
+    fm = pkg.load_force_calibration(os.path.join(G, "calibration_height_to_force.json"))["best_model"]
+    return model, neg, fm
+
+
+def _sensor(pkg, cal, n, cfg, max_batch, ref=None, **kw):
+    ref = pkg.synth.reference_frame(n, **kw) if ref is None else ref
+    return ref, pkg.FtpSensor(ref, pkg.synth.roi_circle(n), cfg, cal[0], cal[1], cal[2], max_batch=max_batch)
+
+
+def _check_frame(out, b, o, n, exact_masks=True, check_argmin=True):
+    """compare GPU outputs of frame b against oracle result dict o"""
+    hm = out["height_map_mm"][b].cpu().numpy()
+    ref = o["height_map_mm_crop"]
+    assert int(out["status"][b]) == 0
+    assert np.array_equal(np.isnan(hm), np.isnan(ref))
+    peak = max(float(np.nanmax(np.abs(ref))), 1e-6)
+    assert float(np.nanmax(np.abs(hm - ref))) <= RTOL * peak
+    rel = out["output_reliable"][b].cpu().numpy().astype(bool)
+    mism = int((rel != o["output_reliable_crop"]).sum())
+    assert mism == 0 if exact_masks else mism <= 2e-4 * n * n
+    s = out["scalars"][b].cpu().numpy()
+    assert int(s[4]) == o["argmax_depth_index"]                       # arg-max depth index: bit-exact
+    v, (ax, ay) = o["argmin_unitless"]
+    if check_argmin:
+        assert int(s[8]) == ay * n + ax                              # arg-min unitless index: bit-exact
+    assert abs(s[7] - v) <= RTOL * max(abs(v), 1e-6)
+    for i, key in ((0, "volume_cm3"), (1, "contact_area_mm2"), (2, "max_depth_mm"), (3, "force_N")):
+        assert abs(s[i] - o[key]) <= RTOL * max(abs(o[key]), 1e-9), key
+    assert s[5] == o["estimated_grating_period_px"] and s[6] == o["mm_per_px"]
+    assert int(s[9]) == int(o["reliable"].sum())
+
+
+@pytest.mark.parametrize("mode", ["scaled", "shipped"])
+def test_full_path_matches_oracle_224(pkg, cal, mode):
+    n, nb = 224, 6
+    cfg = pkg.FtpConfig.scaled(n) if mode == "scaled" else pkg.FtpConfig.as_shipped()
+    ref, sensor = _sensor(pkg, cal, n, cfg, nb)
+    frames = pkg.synth.deformed_batch(n, 0, nb)
+    out = sensor.predict_batch(frames)
+    torch.cuda.synchronize()
+    info = sensor.reference_info
+    rs = O.make_reference_state(ref, *pkg.synth.roi_circle(n), cfg)
+    assert info["peak_refined"] == rs["demod"]["peak_refined"]       # carrier search identical
+    assert info["fft_shape"] == rs["demod"]["fft_shape"]
+    for b in range(nb):
+        o = O.process_frame(frames[b], rs, cfg, *cal, keep_intermediates=True)
+        _check_frame(out, b, o, n)
+        s = out["scalars"][b].cpu().numpy()
+        it = o["inter"]
+        # exact order statistics + NumPy float32 interpolation: thresholds agree to float32 resolution
+        assert abs(s[11] - it["amp_thr"]) <= 2e-6 * abs(it["amp_thr"])
+        assert abs(s[13] - it["bg_med"]) <= 2e-6          # median of an O(1 rad) plane: a few float32 ulps
+        assert int(s[14]) == int(it["demod"]["inter"]["bad"].sum())
+        assert bool(s[10]) == o["flipped"]
+
+
+def test_stage_intermediates_224(pkg, cal):
+    n, nb = 224, 2
+    cfg = pkg.FtpConfig.scaled(n)
+    ref, sensor = _sensor(pkg, cal, n, cfg, nb)
+    frames = pkg.synth.deformed_batch(n, 40, nb)
+    sensor.predict_batch(frames)
+    torch.cuda.synchronize()
+    rs = O.make_reference_state(ref, *pkg.synth.roi_circle(n), cfg)
+    P = n * n
+
+    def plane(name, dt=torch.float32):
+        return sensor.intermediate(name, nb, dt).cpu().numpy()
+
+    cref = sensor.intermediate("cref", 1, torch.float32).cpu().numpy().reshape(n, n, 2)
+    assert np.abs((cref[..., 0] + 1j * cref[..., 1]) - rs["demod"]["field"]).max() <= 1e-5 * np.abs(rs["demod"]["field"]).max()
+    for b in range(nb):
+        o = O.process_frame(frames[b], rs, cfg, *cal, keep_intermediates=True)
+        it, sl = o["inter"], slice(b * P, (b + 1) * P)
+        di = it["demod"]["inter"]
+        assert np.array_equal(plane("bad1", torch.uint8)[sl].reshape(n, n) != 0, di["bad"])          # Sobel, percentiles, dilate
+        assert plane("thr_hi")[b] == np.float32(di["hi_thr"]) and plane("thr_g")[b] == np.float32(di["g_thr"])
+        inp = plane("img")[sl].reshape(n, n)
+        assert np.abs(inp - di["img_inpainted"]).max() <= 1e-5 * 255                                   # Telea inpaint
+        fld = plane("field").reshape(nb, n, n, 2)[b]
+        fo = it["demod"]["field"]
+        assert np.abs((fld[..., 0] + 1j * fld[..., 1]) - fo).max() <= 1e-5 * np.abs(fo).max()          # pruned DFT == fft2/ifft2 path
+        assert np.abs(plane("quality")[sl].reshape(n, n) - it["quality"]).max() <= 1e-5 * it["quality"].max()
+        assert np.array_equal(plane("rel0", torch.uint8)[sl].reshape(n, n) != 0, it["thresholded"])
+        assert np.array_equal(plane("reliable", torch.uint8)[sl].reshape(n, n) != 0, o["reliable"])   # close, CC, chamfer erode
+        uw, uo = plane("unwrapped")[sl].reshape(n, n), it["unwrapped"]
+        assert np.array_equal(np.isnan(uw), np.isnan(uo))
+        m = ~np.isnan(uo)
+        assert np.abs(uw[m] - uo[m]).max() <= 1e-5
+        assert np.array_equal(plane("contact_d", torch.uint8)[sl].reshape(n, n) != 0, o["contact_dilated"])
+        assert np.array_equal(plane("background", torch.uint8)[sl].reshape(n, n) != 0, it["background"])
+        assert np.array_equal(plane("kept", torch.uint8)[sl].reshape(n, n) != 0, o["contact_kept_by_depth"])
+        hu, ho = plane("unitless")[sl].reshape(n, n), o["height_unitless"]
+        assert np.array_equal(np.isnan(hu), np.isnan(ho))
+        assert np.nanmax(np.abs(hu - ho)) <= RTOL * np.nanmax(np.abs(ho))
+
+
+def test_unwrap_with_true_wraps_and_parent_tree(pkg, cal):
+    """Deformations of several 2*pi: the flood must reproduce the oracle's wrap counts exactly."""
+    n, nb = 160, 3
+    cfg = pkg.FtpConfig.scaled(n)
+    ref, sensor = _sensor(pkg, cal, n, cfg, nb, config=5)
+    frames = pkg.synth.deformed_batch(n, 0, nb, config=5, amp_scale=9.0)
+    out = sensor.predict_batch(frames)
+    torch.cuda.synchronize()
+    rs = O.make_reference_state(ref, *pkg.synth.roi_circle(n), cfg)
+    P = n * n
+    uw_all = sensor.intermediate("unwrapped", nb).cpu().numpy()
+    wr_all = sensor.intermediate("wrapped", nb).cpu().numpy()
+    par_all = sensor.intermediate("parent", nb, torch.int32).cpu().numpy()
+    saw_wrap = False
+    for b in range(nb):
+        o = O.process_frame(frames[b], rs, cfg, *cal, keep_intermediates=True)
+        it = o["inter"]
+        uo = it["unwrapped"]
+        uw = uw_all[b * P:(b + 1) * P].reshape(n, n)
+        wr = wr_all[b * P:(b + 1) * P].reshape(n, n)
+        assert np.array_equal(np.isnan(uw), np.isnan(uo))
+        m = ~np.isnan(uo)
+        k_gpu = np.rint((uw[m] - wr[m]) / (2 * np.pi))
+        k_ora = np.rint((uo[m] - it["wrapped"][m]) / (2 * np.pi))
+        assert np.array_equal(k_gpu, k_ora)
+        saw_wrap |= bool(np.any(k_ora != 0))
+        assert np.abs(uw[m] - uo[m]).max() <= 2e-5
+        # the spanning tree itself (parent of every pixel) equals the reference's heap order
+        from oracle import cvlite
+        _, par_o, _ = cvlite.unwrap_quality_guided(it["wrapped"], o["reliable"], it["quality"], want_tree=True)
+        qg = sensor.intermediate("quality", nb).cpu().numpy()[b * P:(b + 1) * P].reshape(n, n)
+        if np.array_equal(qg, it["quality"]):       # identical keys -> identical tree, bit for bit
+            assert np.array_equal(par_all[b * P:(b + 1) * P].reshape(n, n), par_o)
+        _check_frame(out, b, o, n)
+    assert saw_wrap
+
+
+def test_input_formats_agree(pkg, cal):
+    n, nb = 128, 2
+    cfg = pkg.FtpConfig.scaled(n)
+    ref, sensor = _sensor(pkg, cal, n, cfg, nb)
+    g = pkg.synth.deformed_batch(n, 7, nb)
+    base = sensor.predict_batch(g)["height_map_mm"].clone()
+    bgr = np.repeat(g[..., None], 3, axis=-1)
+    for frames in (torch.from_numpy(g).to(torch.float16), bgr, torch.from_numpy(bgr).to(torch.float16)):
+        got = sensor.predict_batch(frames)["height_map_mm"]
+        assert torch.equal(torch.nan_to_num(got, nan=-1.0), torch.nan_to_num(base, nan=-1.0))
+    # a genuinely coloured frame goes through the fixed-point BGR2GRAY of OpenCV 4.x
+    rng = np.random.default_rng(3)
+    col = np.clip(bgr.astype(np.int32) + rng.integers(-6, 7, size=bgr.shape), 0, 255).astype(np.uint8)
+    gray = ((col[..., 0].astype(np.int64) * 3735 + col[..., 1].astype(np.int64) * 19235 + col[..., 2].astype(np.int64) * 9798 + (1 << 14)) >> 15).astype(np.uint8)
+    a = sensor.predict_batch(col)["height_map_mm"].clone()
+    b = sensor.predict_batch(gray)["height_map_mm"]
+    assert torch.equal(torch.nan_to_num(a, nan=-1.0), torch.nan_to_num(b, nan=-1.0))
+
+
+def test_edge_cases(pkg, cal):
+    n = 128
+    cfg = pkg.FtpConfig.scaled(n)
+    ref, sensor = _sensor(pkg, cal, n, cfg, 4)
+    rs = O.make_reference_state(ref, *pkg.synth.roi_circle(n), cfg)
+    # deformed == reference: zero phase everywhere -> no contact
+    out = sensor.predict_batch(ref[None])
+    o = O.process_frame(ref, rs, cfg, *cal)
+    # a flat (noise-level) height field has no meaningful arg-min: index not compared here
+    _check_frame(out, 0, o, n, check_argmin=False)
+    assert float(out["scalars"][0, 3]) == o["force_N"]
+    # featureless frame: upstream returns None when the reliable mask is empty (shape_ftp.py:1677-1679)
+    blank = np.full((n, n), 90, np.uint8)
+    # (a constant frame demodulates to pure rounding noise, so its map is not comparable; the call must
+    #  complete with a valid status and the NaN-outside-ROI layout)
+    ob = sensor.predict_batch(blank[None])
+    torch.cuda.synchronize()
+    assert int(ob["status"][0]) in (0, 1)
+    hm_blank = ob["height_map_mm"][0].cpu().numpy()
+    assert np.all(np.isnan(hm_blank[~rs["roi"]]))
+    assert int(ob["status"][0]) == 1 or not np.any(np.isnan(hm_blank[rs["roi"]]))
+    # error behaviour of the boundary
+    with pytest.raises(RuntimeError):
+        sensor.predict_batch(np.zeros((1, n + 2, n), np.uint8))          # size mismatch (shape_ftp.py:1477)
+    with pytest.raises(RuntimeError):
+        sensor.predict_batch(np.zeros((5, n, n), np.uint8))              # batch > max_batch
+    with pytest.raises(ValueError):
+        pkg.FtpSensor(ref, pkg.synth.roi_circle(n), cfg, {"type": "nope", "params": {}}, True, cal[2], max_batch=1)
+    with pytest.raises(ValueError):
+        sensor.predict_batch(np.zeros((1, n, n), np.float32))
+    # single-frame API returns the reference's result dict
+    r1 = sensor.predict(pkg.synth.deformed_frame(n, 1))
+    assert set(["height_map_mm_crop", "roi_eroded_crop", "output_reliable_crop", "estimated_grating_period_px"]) <= set(r1)
+    assert r1["height_map_mm_crop"].dtype == np.float32 and r1["roi_eroded_crop"].dtype == bool
+    assert np.array_equal(r1["roi_eroded_crop"], rs["roi"])
+
+
+def test_force_tail_on_device(pkg):
+    g = np.load(os.path.join(G, "ref_numpy_small.npz"))
+    h = g["tail_h"]
+    for sign, key in ((1, "tail_res"), (-1, "tail_res_neg")):
+        got = pkg.depth_map_to_volume_cm3(sign * h, np.isfinite(h), 0.0303784, 0.01)
+        assert got[1] == g[key][1] and got[2] == g[key][2]               # area, max depth: exact
+        assert abs(got[0] - g[key][0]) <= 1e-6 * g[key][0]               # float32 sum order
+    assert pkg.depth_map_to_volume_cm3(h * 0, np.isfinite(h), 0.0303784, 0.01) == (0.0, 0.0, 0.0)
+    d = np.load(os.path.join(G, "ref_tail_demo_E_small.npz"))
+    got = pkg.depth_map_to_volume_cm3(d["height"], None, float(d["mm_per_px"][0]), 0.01)   # roi = isfinite (multimodal_sensor.py:388)
+    assert got[1] == d["tail"][1] and got[2] == d["tail"][2]
+    assert abs(got[0] - d["tail"][0]) <= 1e-6 * d["tail"][0]
+    batch = np.stack([h, -h, h * 0])
+    res = pkg.depth_map_to_volume_cm3(batch, None, 0.0303784, 0.01)
+    assert res.shape == (3, 3) and res[2].tolist() == [0.0, 0.0, 0.0]
+
+
+def test_full_batch_properties_256(pkg, cal):
+    """BASELINE size (batch 256 at 224x224): determinism, batch-position independence, replicated frames."""
+    n, B = 224, 256
+    cfg = pkg.FtpConfig.scaled(n)
+    ref, sensor = _sensor(pkg, cal, n, cfg, B)
+    base = pkg.synth.deformed_batch(n, 100, 16)
+    frames = torch.from_numpy(np.concatenate([base] * 16, axis=0)).cuda()
+    o1 = {k: v.clone() for k, v in sensor.predict_batch(frames).items()}
+    o2 = sensor.predict_batch(frames)
+    torch.cuda.synchronize()
+    assert int((o1["status"] != 0).sum()) == 0
+    for k in ("height_map_mm", "output_reliable", "scalars"):
+        a, b = o1[k], o2[k]
+        if a.is_floating_point():
+            a, b = torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)
+        assert torch.equal(a, b), k                                     # run-to-run bit identical
+    hm = torch.nan_to_num(o1["height_map_mm"], nan=-7.0)
+    for rep in range(1, 16):
+        assert torch.equal(hm[rep * 16:(rep + 1) * 16], hm[:16])         # position in the batch does not matter
+    small = sensor.predict_batch(frames[3:5])
+    assert torch.equal(torch.nan_to_num(small["height_map_mm"], nan=-7.0), hm[3:5])
+    # spot-check three frames of the big batch against the oracle
+    rs = O.make_reference_state(ref, *pkg.synth.roi_circle(n), cfg)
+    for b in (0, 7, 15):
+        _check_frame(o1, 240 + b, O.process_frame(base[b], rs, cfg, *cal), n)

@@ -26,10 +26,10 @@ namespace {
 
 struct GKern { float *d = nullptr; int k = 0; };
 
-enum Stage { ST_GRAY_BAD = 0, ST_INPAINT, ST_PREPROC, ST_DEMOD, ST_RELIABLE, ST_UNWRAP, ST_DETREND, ST_SMOOTH_FLIP, ST_COMPOSE, ST_MM_BLOB,
+enum Stage { ST_GRAY_BAD = 0, ST_INPAINT, ST_PREPROC, ST_DEMOD, ST_RELIABLE, ST_UNWRAP, ST_UNWRAP_TREE, ST_DETREND, ST_SMOOTH_FLIP, ST_COMPOSE, ST_MM_BLOB,
              ST_TAIL, ST_COUNT };
-const char *kStageNames[ST_COUNT] = {"gray+badpix", "inpaint", "illum+blur+apod+median", "pruned-dft demod", "reliable mask",
-                                     "unwrap", "detrend (3x IRLS)", "smooth+flip", "frontier+compose", "mm+blob filter", "tail"};
+const char *kStageNames[ST_COUNT] = {"gray+badpix", "inpaint (k_telea)", "illum+blur+apod+median", "pruned-dft demod", "reliable mask",
+                                     "unwrap flood (k_unwrap_flood)", "unwrap tree", "detrend (3x IRLS)", "smooth+flip", "frontier+compose", "mm+blob filter", "tail"};
 
 int cv_round(double v) { return (int)std::nearbyint(v); }
 
@@ -545,7 +545,8 @@ int vistaf_ftp_predict_batch(vistaf_ftp_handle *hd, const void *d_frames, int fo
 
     // ---- unwrap (shape_ftp.py:1702)
     if (timed) hipEventRecord(hd->ev[ST_UNWRAP], st);
-    launch_unwrap(hd->wrapped, qual, hd->reliable, hd->unwrapped, hd->parent, hd->unwrap_scratch, hd->status, B, h, w, st);
+    launch_unwrap(hd->wrapped, qual, hd->reliable, hd->unwrapped, hd->parent, hd->unwrap_scratch, hd->status, B, h, w, st,
+                  timed ? hd->ev[ST_UNWRAP_TREE] : nullptr);
 
     // ---- plane removal + two-pass detrend (shape_ftp.py:1706, :1716-1751)
     if (timed) hipEventRecord(hd->ev[ST_DETREND], st);

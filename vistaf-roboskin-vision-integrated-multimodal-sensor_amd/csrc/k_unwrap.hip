@@ -123,17 +123,31 @@ __global__ __launch_bounds__(64) void k_unwrap_flood(const float *__restrict__ q
 // Words written by other threads of the workgroup are read with agent-scope relaxed atomic loads.
 __device__ inline int ld_i32(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__global__ __launch_bounds__(1024) void k_unwrap_tree(const float *__restrict__ wrapped_all, int32_t *parent_all, int32_t *incA_all,
-                                                      int32_t *parB_all, int32_t *incB_all, float *__restrict__ unwrapped_all, int P)
+// ppar_all (optional): parents in PADDED (h+2)x(w+2) index space as written by k_unwrap_flood_ranked;
+// they are converted here and stored to parent_all (the plane the parity tests read back).
+__global__ __launch_bounds__(1024) void k_unwrap_tree(const float *__restrict__ wrapped_all, int32_t *parent_all,
+                                                      const int32_t *__restrict__ ppar_all, size_t gstride, int32_t *parA_all,
+                                                      int32_t *incA_all, int32_t *parB_all, int32_t *incB_all,
+                                                      float *__restrict__ unwrapped_all, int h, int w)
 {
     __shared__ int s_changed;
     const size_t b = blockIdx.x;
+    const int P = h * w;
     const float *wrapped = wrapped_all + b * (size_t)P;
-    int32_t *pi = parent_all + b * (size_t)P, *ii = incA_all + b * (size_t)P;
-    int32_t *po = parB_all + b * (size_t)P, *io = incB_all + b * (size_t)P;
+    int32_t *tree = parent_all + b * (size_t)P;
+    int32_t *pi = parA_all + b * gstride, *ii = incA_all + b * gstride;
+    int32_t *po = parB_all + b * gstride, *io = incB_all + b * gstride;
     const double twopi = 6.283185307179586476925286766559, pi_d = 3.14159265358979323846;
     for (int p = threadIdx.x; p < P; p += blockDim.x) {
-        int par = pi[p];
+        int par;
+        if (ppar_all) {
+            const int W2 = w + 2;
+            int y = p / w, x = p - y * w;
+            int pp = ppar_all[b * gstride + (size_t)(y + 1) * W2 + x + 1];
+            par = pp < 0 ? -1 : (pp / W2 - 1) * w + (pp % W2 - 1);
+            tree[p] = par;
+        } else par = tree[p];
+        pi[p] = par;
         int v = 0;
         if (par >= 0 && par != p) {
             double d = (double)wrapped[p] - (double)wrapped[par];
@@ -180,9 +194,14 @@ __global__ __launch_bounds__(1024) void k_unwrap_tree(const float *__restrict__ 
 
 size_t unwrap_scratch_bytes_per_frame(int h, int w)
 {
-    size_t P = (size_t)h * w;
-    return P /*st*/ + 3 * P * sizeof(uint32_t) /*frontier keys+idx, reused as jump buffers*/ + 256;
+    size_t P = (size_t)h * w, EN = (size_t)(h + 2) * (w + 2);
+    return P /*st*/ + 5 * EN * sizeof(uint32_t) /*sort / frontier / jump buffers / padded parents*/ + 2 * EN + 16 /*rank codes*/ + 64 /*seed*/ + 512;
 }
+
+bool unwrap_ranked_supported(int h, int w);
+void launch_unwrap_ranked(const float *quality, const uint8_t *mask, uint32_t *g0, uint32_t *g1, uint32_t *g2, uint32_t *g3,
+                          int32_t *ppar, size_t gstride, uint16_t *rank16, int32_t *seed, int32_t *status, int B, int h, int w,
+                          hipStream_t st);
 
 static int unwrap_lds_cap(int P)
 {
@@ -192,16 +211,26 @@ static int unwrap_lds_cap(int P)
 }
 
 void launch_unwrap(const float *wrapped, const float *quality, const uint8_t *mask, float *unwrapped, int32_t *parent,
-                   void *scratch, int32_t *status, int B, int h, int w, hipStream_t st)
+                   void *scratch, int32_t *status, int B, int h, int w, hipStream_t st, hipEvent_t ev_mid)
 {
     int P = h * w;
     size_t n = (size_t)B * P;
-    // scratch: [B*P st bytes][B*P u32][B*P u32][B*P u32]
+    size_t EN = (size_t)(h + 2) * (w + 2);           // per-frame stride of the uint32 planes
+    // scratch: [B*P st bytes][5 x B*EN u32][B*EN u16 rank codes][B seeds]
     uint8_t *gst = (uint8_t *)scratch;
     uint32_t *g0 = (uint32_t *)((uint8_t *)scratch + ((n + 255) & ~(size_t)255));
-    uint32_t *g1 = g0 + n, *g2 = g1 + n;
+    size_t gn = (size_t)B * EN;
+    uint32_t *g1 = g0 + gn, *g2 = g1 + gn, *g3 = g2 + gn, *g4 = g3 + gn;
     int cap = unwrap_lds_cap(P);
-    if (cap > 0) {
+    const int32_t *ppar = nullptr;
+    if (unwrap_ranked_supported(h, w)) {
+        uint8_t *after = (uint8_t *)(g4 + gn);
+        after = (uint8_t *)(((uintptr_t)after + 255) & ~(uintptr_t)255);
+        uint16_t *rank16 = (uint16_t *)after;
+        int32_t *seed = (int32_t *)(after + (((gn + 8 * (size_t)B) * 2 + 255) & ~(size_t)255));
+        launch_unwrap_ranked(quality, mask, g0, g1, g2, g3, (int32_t *)g4, EN, rank16, seed, status, B, h, w, st);
+        ppar = (const int32_t *)g4;
+    } else if (cap > 0) {
         static bool attr_set = false;
         if (!attr_set) { hipFuncSetAttribute((const void *)k_unwrap_flood<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
         size_t lds = (size_t)cap * 8 + ((P + 15) & ~15);
@@ -209,7 +238,9 @@ void launch_unwrap(const float *wrapped, const float *quality, const uint8_t *ma
     } else {
         hipLaunchKernelGGL(k_unwrap_flood<false>, dim3(B), dim3(64), 0, st, quality, mask, parent, gst, g0, g1, P, status, h, w);
     }
-    hipLaunchKernelGGL(k_unwrap_tree, dim3(B), dim3(1024), 0, st, wrapped, parent, (int32_t *)g0, (int32_t *)g1, (int32_t *)g2, unwrapped, P);
+    if (ev_mid) hipEventRecord(ev_mid, st);
+    hipLaunchKernelGGL(k_unwrap_tree, dim3(B), dim3(1024), 0, st, wrapped, parent, ppar, EN, (int32_t *)g3, (int32_t *)g0, (int32_t *)g1,
+                       (int32_t *)g2, unwrapped, h, w);
 }
 
 }  // namespace vf

@@ -1,0 +1,291 @@
+// Fast path of unwrap_quality_guided (shape_ftp.py:1043-1080) for frames whose padded plane
+// (h+2)*(w+2) has at most 65533 pixels.
+//
+// k_unwrap_rank   (1024 threads / frame) replaces each masked pixel's float quality by its RANK in the
+//                 frame's total order (q ascending, ties: larger pixel index first, so that the larger
+//                 rank is exactly the reference heap's higher priority "-q, then smaller (y, x)").
+//                 Stable LSD radix sort, 4-bit digits, thread-contiguous chunks.  The rank codes are
+//                 written into a plane padded by one pixel of zeros on every side.
+// k_unwrap_flood_ranked (one wavefront / frame) holds the whole padded frame in LDS as one uint16 per
+//                 pixel (0 outside mask / border, 1 visited, 2 in frontier, >= 3 untouched with
+//                 rank = v - 3).  The sequential growth loop touches no global memory except the
+//                 parent store, needs no bounds checks or divisions (the border is "outside"), reads the
+//                 8 neighbours with 8 lanes, and finds the frontier maximum with a packed b128 scan of
+//                 uint16 keys plus one DPP wave reduction.  Keys are unique: no tie handling.
+#include "kernels.hpp"
+
+namespace vf {
+
+constexpr int RK_T = 1024;
+
+// ---- DPP wave reductions (gfx9 row / bcast controls) -------------------------------------------------
+__device__ inline uint32_t dpp_max_u32(uint32_t v)
+{
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false); v = t > v ? t : v;    // quad_perm [1,0,3,2]
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false); v = t > v ? t : v;    // quad_perm [2,3,0,1]
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, false); v = t > v ? t : v;   // row_half_mirror
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xf, 0xf, false); v = t > v ? t : v;   // row_mirror
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xa, 0xf, false); v = t > v ? t : v;   // row_bcast15 -> rows 1,3
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false); v = t > v ? t : v;   // row_bcast31 -> rows 2,3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// maximum over lanes 0..7 (valid in lane 0..7), returned uniform
+__device__ inline uint32_t dpp_max8_u32(uint32_t v)
+{
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false); v = t > v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false); v = t > v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, false); v = t > v ? t : v;
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+// ---- ranks -------------------------------------------------------------------------------------------
+// rank plane layout: [(h+2) x (w+2)] uint16 (frame stride padded to 8 elements), border = 0.
+// Sort structure: each of the 16 waves owns a contiguous range of the element array and walks it in
+// 64-element tiles (coalesced, L1-bypassing loads of data other waves wrote in the previous pass).
+// Counting uses a per-wave 16-bin LDS histogram; the stable scatter ranks a lane among the lanes of its
+// tile that share its digit with four ballots (peer mask) + mbcnt.
+__device__ inline uint32_t ld_u32c(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(RK_T) void k_unwrap_rank(const float *__restrict__ quality_all, const uint8_t *__restrict__ mask_all,
+                                                      uint32_t *kA_all, uint32_t *iA_all, uint32_t *kB_all, uint32_t *iB_all,
+                                                      size_t gstride, uint16_t *__restrict__ rank_all, int32_t *__restrict__ seed_out,
+                                                      int h, int w)
+{
+    __shared__ uint32_t whist[16][16];     // [wave][digit] counts, then exclusive offsets
+    __shared__ uint32_t wcount[16];
+    const size_t b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int P = h * w, W2 = w + 2, EN = (h + 2) * W2;
+    const float *q = quality_all + b * (size_t)P;
+    const uint8_t *m = mask_all + b * (size_t)P;
+    uint32_t *kA = kA_all + b * gstride, *iA = iA_all + b * gstride, *kB = kB_all + b * gstride, *iB = iB_all + b * gstride;
+    uint16_t *rk = rank_all + b * (size_t)((EN + 7) & ~7);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    for (int i = tid; i < EN; i += RK_T) rk[i] = 0;
+    // 1. compact masked pixels in DESCENDING pixel order; wave `wid` owns reversed positions [r0, r1)
+    const int Lw = (((P + 15) / 16) + 63) & ~63;
+    const int r0 = min(P, wid * Lw), r1 = min(P, r0 + Lw);
+    uint32_t c = 0;
+    for (int rb = r0; rb < r1; rb += 64) {
+        int r = rb + lane;
+        bool in = r < r1 && m[P - 1 - r] != 0;
+        c += (uint32_t)__popcll(__ballot(in));
+    }
+    if (lane == 0) wcount[wid] = c;
+    __syncthreads();
+    uint32_t off = 0, n = 0;
+    for (int i = 0; i < 16; i++) { uint32_t x = wcount[i]; if (i < wid) off += x; n += x; }
+    for (int rb = r0; rb < r1; rb += 64) {
+        int r = rb + lane;
+        bool in = r < r1 && m[P - 1 - r] != 0;
+        unsigned long long bm = __ballot(in);
+        if (in) {
+            int p = P - 1 - r;
+            int y = p / w, x = p - y * w;
+            uint32_t o = off + (uint32_t)__popcll(bm & lt_mask);
+            kA[o] = f2key(q[p]);
+            iA[o] = (uint32_t)((y + 1) * W2 + x + 1);
+        }
+        off += (uint32_t)__popcll(bm);
+    }
+    if (tid == 0 && n == 0) seed_out[b] = -1;
+    __threadfence();
+    __syncthreads();
+    if (n == 0) return;
+
+    // 2. stable LSD radix sort, 8 passes of 4 bits; wave `wid` owns elements [e0, e1)
+    const int Mw = ((((int)n + 15) / 16) + 63) & ~63;
+    const int e0 = min((int)n, wid * Mw), e1 = min((int)n, e0 + Mw);
+    uint32_t *ks = kA, *is = iA, *kd = kB, *id = iB;
+    for (int pass = 0; pass < 8; pass++) {
+        const int shift = pass * 4;
+        if (lane < 16) whist[wid][lane] = 0;
+        for (int eb = e0; eb < e1; eb += 64) {
+            int e = eb + lane;
+            if (e < e1) atomicAdd(&whist[wid][(ld_u32c(&ks[e]) >> shift) & 15u], 1u);
+        }
+        __syncthreads();
+        // exclusive offsets in (digit-major, wave-minor) order, computed by the first 256 threads
+        if (tid < 256) {
+            int d = tid >> 4, wv = tid & 15;
+            uint32_t v = whist[wv][d];
+            uint32_t incl = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+            if (lane == 63) wcount[tid >> 6] = incl;
+            whist[wv][d] = incl - v;       // wave-local exclusive prefix; wave totals added after the block barrier
+        }
+        __syncthreads();
+        if (tid < 256) {
+            uint32_t add = 0;
+            for (int i = 0; i < (tid >> 6); i++) add += wcount[i];
+            whist[tid & 15][tid >> 4] += add;
+        }
+        __syncthreads();
+        for (int eb = e0; eb < e1; eb += 64) {
+            int e = eb + lane;
+            bool ok = e < e1;
+            uint32_t k = ok ? ld_u32c(&ks[e]) : 0u, ix = ok ? ld_u32c(&is[e]) : 0u;
+            uint32_t d = (k >> shift) & 15u;
+            unsigned long long peers = __ballot(ok);
+#pragma unroll
+            for (int bit = 0; bit < 4; bit++) {
+                unsigned long long bm = __ballot(ok && ((d >> bit) & 1u));
+                peers &= ((d >> bit) & 1u) ? bm : ~bm;
+            }
+            uint32_t base = whist[wid][d];
+            uint32_t rnk = (uint32_t)__popcll(peers & lt_mask);
+            if (ok) { kd[base + rnk] = k; id[base + rnk] = ix; }
+            if (ok && rnk == 0) whist[wid][d] = base + (uint32_t)__popcll(peers);
+        }
+        __threadfence();
+        __syncthreads();
+        uint32_t *t = ks; ks = kd; kd = t;
+        t = is; is = id; id = t;
+    }
+    // 3. rank = sorted position (ascending priority); uint16 code = rank + 3
+    for (int e = tid; e < (int)n; e += RK_T) {
+        uint32_t ix = ld_u32c(&is[e]);
+        rk[ix] = (uint16_t)(e + 3);
+        if (e == (int)n - 1) seed_out[b] = (int32_t)ix;
+    }
+}
+
+// ---- growth --------------------------------------------------------------------------------------------
+// ppar[padded pixel] = padded index of its parent (own index for the seed), -1 where never reached
+__global__ __launch_bounds__(64) void k_unwrap_flood_ranked(const uint16_t *__restrict__ rank_all, const int32_t *__restrict__ seed_in,
+                                                            int32_t *__restrict__ ppar_all, size_t gstride, int cap, int32_t *status,
+                                                            int h, int w)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = threadIdx.x;
+    const size_t b = blockIdx.x;
+    const int W2 = w + 2, EN = (h + 2) * W2;
+    const int EN8 = (EN + 7) & ~7;
+    uint16_t *kp = (uint16_t *)lds_raw;                // [EN8] pixel state / rank code
+    uint32_t *fe = (uint32_t *)(kp + EN8);             // [cap] frontier entries: rank code << 16 | padded pixel index (0 = empty)
+    int32_t *ppar = ppar_all + b * gstride;
+    const uint16_t *rk = rank_all + b * (size_t)((EN + 7) & ~7);   // frame stride padded to 16 bytes
+
+    {
+        const uint4 *src = (const uint4 *)rk;
+        uint4 *dst = (uint4 *)kp;
+        int nv = EN >> 3;
+        for (int i = lane; i < nv; i += 64) dst[i] = src[i];
+        for (int p = (nv << 3) + lane; p < EN; p += 64) kp[p] = rk[p];
+    }
+    {
+        uint4 z = make_uint4(0, 0, 0, 0);
+        uint4 *dst = (uint4 *)fe;
+        for (int i = lane; i < (cap >> 2); i += 64) dst[i] = z;
+    }
+    for (int p = lane; p < EN; p += 64) ppar[p] = -1;
+    __syncthreads();
+    int cur = seed_in[b];
+    if (cur < 0) return;                               // empty mask (shape_ftp.py:1047-1048)
+    // neighbour offsets of lanes 0..7 in lexicographic (dy, dx) order
+    int doff = 0;
+    {
+        int l = (lane & 7) < 4 ? (lane & 7) : (lane & 7) + 1;
+        doff = (l / 3 - 1) * W2 + (l % 3 - 1);
+    }
+    int F = 0;
+    bool first = true, overflow = false;
+    if (lane == 0) kp[cur] = 1;
+    const uint4 *fe4 = (const uint4 *)fe;
+
+    for (;;) {
+        // all LDS reads of the step are issued back to back (one round trip): the 8 neighbours of `cur`,
+        // the frontier entries, and the last entry (it fills the hole if an old entry is popped)
+        uint32_t v = 0;
+        int np = cur + doff;
+        if (lane < 8) v = kp[np];
+        uint32_t lastv = F > 0 ? fe[F - 1] : 0u;
+        uint32_t best = 0, bv0 = 0, bv1 = 0, bv2 = 0, bv3 = 0;
+        int bbase = 0;
+        // four independent b128 loads per trip are issued before the first use (cap is a multiple of 1024 and
+        // slots >= F are zero, so over-reading a trip is harmless)
+        for (int base = 0; base < F; base += 1024) {
+            const uint4 *src = fe4 + (base >> 2) + lane;
+            uint4 k0 = src[0], k1 = src[64], k2 = src[128], k3 = src[192];
+#define VF_SCAN4(kv, off)                                                                                      \
+            {                                                                                                  \
+                uint32_t m01 = kv.x > kv.y ? kv.x : kv.y, m23 = kv.z > kv.w ? kv.z : kv.w;                       \
+                uint32_t m = m01 > m23 ? m01 : m23;                                                            \
+                if (m > best) { best = m; bbase = base + (off); bv0 = kv.x; bv1 = kv.y; bv2 = kv.z; bv3 = kv.w; } \
+            }
+            VF_SCAN4(k0, 0) VF_SCAN4(k1, 256) VF_SCAN4(k2, 512) VF_SCAN4(k3, 768)
+#undef VF_SCAN4
+        }
+        unsigned long long vis = __ballot(v == 1);
+        bool fresh = v >= 3;
+        unsigned long long fb = __ballot(fresh);
+        int par = cur;
+        if (!first) par = cur + __builtin_amdgcn_readlane(doff, __ffsll((long long)vis) - 1);
+        first = false;
+        if (lane == 0) ppar[cur] = par;
+        uint32_t mq = dpp_max_u32(best);               // rank code in the high half, pixel index in the low half
+        uint32_t nk = fresh ? v : 0u;
+        uint32_t nm = dpp_max8_u32(nk);
+        if ((mq | nm) == 0) break;                     // frontier exhausted
+        int next;
+        unsigned long long app = fb;                   // lanes whose neighbour is appended to the frontier
+        if (nm > (mq >> 16)) {
+            int wl = __ffsll((long long)__ballot(fresh && nk == nm)) - 1;
+            next = cur + __builtin_amdgcn_readlane(doff, wl);
+            app &= ~(1ull << wl);
+        } else {
+            next = (int)(mq & 0xffffu);
+            int wl = __ffsll((long long)__ballot(best == mq)) - 1;
+            int sub = bv0 == mq ? 0 : bv1 == mq ? 1 : bv2 == mq ? 2 : 3;
+            int slot = __builtin_amdgcn_readlane(bbase + (lane << 2) + sub, wl);
+            int last = F - 1;
+            if (lane == 0) { fe[slot] = lastv; fe[last] = 0; }     // slot == last: the second store wins
+            F = last;
+        }
+        int napp = (int)__popcll(app);
+        if (F + napp > cap) { overflow = true; break; }
+        if ((app >> lane) & 1ull) {
+            int pos = F + (int)__popcll(app & ((1ull << lane) - 1ull));
+            fe[pos] = (nk << 16) | (uint32_t)np;
+            kp[np] = 2;
+        }
+        F += napp;
+        cur = next;
+        if (lane == 0) kp[cur] = 1;
+    }
+    if (overflow && lane == 0) status[b] = 2;
+}
+
+static int ranked_cap(int EN)
+{
+    long plane = (long)(((EN + 7) & ~7)) * 2;
+    long avail = 160 * 1024 - plane;
+    long cap = (avail / 4) & ~1023L;
+    return (int)cap;
+}
+
+bool unwrap_ranked_supported(int h, int w)
+{
+    long EN = (long)(h + 2) * (w + 2);
+    return EN <= 65533 && ranked_cap((int)EN) >= 2048;
+}
+
+// g0..g3: uint32 planes of gstride elements per frame (sort ping-pong); ppar: int32 plane of gstride elements
+void launch_unwrap_ranked(const float *quality, const uint8_t *mask, uint32_t *g0, uint32_t *g1, uint32_t *g2, uint32_t *g3,
+                          int32_t *ppar, size_t gstride, uint16_t *rank16, int32_t *seed, int32_t *status, int B, int h, int w,
+                          hipStream_t st)
+{
+    int EN = (h + 2) * (w + 2);
+    int cap = ranked_cap(EN);
+    hipLaunchKernelGGL(k_unwrap_rank, dim3(B), dim3(RK_T), 0, st, quality, mask, g0, g1, g2, g3, gstride, rank16, seed, h, w);
+    static bool attr_set = false;
+    if (!attr_set) { hipFuncSetAttribute((const void *)k_unwrap_flood_ranked, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    size_t lds = (size_t)((EN + 7) & ~7) * 2 + (size_t)cap * 4;
+    hipLaunchKernelGGL(k_unwrap_flood_ranked, dim3(B), dim3(64), lds, st, rank16, seed, ppar, gstride, cap, status, h, w);
+}
+
+}  // namespace vf

@@ -37,10 +37,11 @@ def reference_frame(n: int, config: int = 3, period=None) -> np.ndarray:
     return _base(n, 0.0, rng, period)
 
 
-def deformed_frame(n: int, index: int, config: int = 3, period=None) -> np.ndarray:
+def deformed_frame(n: int, index: int, config: int = 3, period=None, amp_scale: float = 1.0) -> np.ndarray:
+    """amp_scale > 1 multiplies the phase amplitude (e.g. 8 gives genuine 2*pi wraps for unwrap tests)."""
     rng = np.random.default_rng(1000 * config + index)
     cx, cy, r = roi_circle(n)
-    amp = rng.uniform(0.2, 1.2)
+    amp = rng.uniform(0.2, 1.2) * amp_scale
     rad = 0.5 * r * np.sqrt(rng.uniform(0.0, 1.0))
     ang = rng.uniform(0.0, 2.0 * np.pi)
     x0, y0 = cx + rad * np.cos(ang), cy + rad * np.sin(ang)
@@ -50,5 +51,5 @@ def deformed_frame(n: int, index: int, config: int = 3, period=None) -> np.ndarr
     return _base(n, phi, rng, period)
 
 
-def deformed_batch(n: int, start: int, count: int, config: int = 3, period=None) -> np.ndarray:
-    return np.stack([deformed_frame(n, start + i, config, period) for i in range(count)], axis=0)
+def deformed_batch(n: int, start: int, count: int, config: int = 3, period=None, amp_scale: float = 1.0) -> np.ndarray:
+    return np.stack([deformed_frame(n, start + i, config, period, amp_scale) for i in range(count)], axis=0)
