@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -64,7 +65,7 @@ struct vistaf_ftp_handle {
     uint8_t *bad0, *bad1, *rel0, *rel1, *rel2, *reliable, *contact, *contact_d, *background, *cand, *kept;
     int32_t *labels, *area, *rowdist, *parent;
     unsigned int *peak_bits;
-    void *inpaint_scratch, *unwrap_scratch;
+    void *inpaint_scratch, *inpaint_cl_scratch, *unwrap_scratch;
     // small per-frame arrays
     float *thr_hi, *thr_g, *mu, *amp_thr, *thr3, *thr_used, *bg_med, *core_thr, *core_med, *coef;
     int *cnt_a, *cnt_valid, *rel_count, *contact_count, *bg_count, *bad_count, *flipped;
@@ -163,7 +164,18 @@ void preprocess(vistaf_ftp_handle *hd, const void *frames, int format, int B, hi
         if (src != hd->bad1) hipMemcpyAsync(hd->bad1, src, (size_t)B * P, hipMemcpyDeviceToDevice, st);
         launch_count_u8(hd->bad1, hd->bad_count, B, P, st);
         if (timed) hipEventRecord(hd->ev[ST_INPAINT], st);
-        launch_inpaint_telea(hd->img, hd->bad1, cv_round((double)c.bad_inpaint_radius), hd->inpaint_scratch, hd->status, B, h, w, st);
+        {
+            int range = std::min(100, std::max(1, cv_round((double)c.bad_inpaint_radius)));   // cv::inpaint clamps the radius
+            const uint8_t *seq_mask = hd->bad1;
+            static int use_cl = -1;   // cluster-parallel front end: VISTAF_INPAINT=cluster (off by default: see DESIGN.md)
+            if (use_cl < 0) { const char *ev = getenv("VISTAF_INPAINT"); use_cl = (ev && !strcmp(ev, "cluster")) ? 1 : 0; }
+            if (use_cl && inpaint_clusters_supported(range)) {
+                uint8_t *bad_big = nullptr;
+                launch_inpaint_clusters(hd->img, hd->bad1, range, hd->inpaint_cl_scratch, &bad_big, B, h, w, st);
+                seq_mask = bad_big;     // only clusters too large for an LDS window remain for the sequential kernel
+            }
+            launch_inpaint_telea(hd->img, seq_mask, range, hd->inpaint_scratch, hd->status, B, h, w, st);
+        }
     } else if (timed) hipEventRecord(hd->ev[ST_INPAINT], st);
     if (timed) hipEventRecord(hd->ev[ST_PREPROC], st);
     blur(hd, hd->img, hd->blurA, hd->g_illum, B, st);
@@ -338,6 +350,7 @@ int vistaf_ftp_create(const vistaf_ftp_config *cfg, int h, int w, int cx, int cy
     {
         void *p = nullptr;
         TRY(dalloc(hd, (uint8_t **)&p, inpaint_scratch_bytes_per_frame(h, w) * max_batch)); hd->inpaint_scratch = p;
+        TRY(dalloc(hd, (uint8_t **)&p, inpaint_cl_scratch_bytes_per_frame(h, w) * max_batch + 2048)); hd->inpaint_cl_scratch = p;
         TRY(dalloc(hd, (uint8_t **)&p, unwrap_scratch_bytes_per_frame(h, w) * max_batch + 1024)); hd->unwrap_scratch = p;
     }
     int pmax = 2 * bwp + 1;

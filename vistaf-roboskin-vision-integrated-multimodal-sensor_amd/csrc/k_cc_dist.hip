@@ -75,8 +75,90 @@ __global__ __launch_bounds__(1024) void k_cc_label(const uint8_t *__restrict__ m
         if (m[p]) { int r = cc_find(L, p); if (r != p) atomicMin(&L[p], r); }
 }
 
+// ---- LDS-resident variant for frames of at most 65535 pixels: the whole label forest lives in LDS as one
+// uint16 per pixel, so finds and unions are LDS round trips instead of L2 round trips.  LDS has no 16-bit
+// atomics: the "hang root b under a" step is a 32-bit CAS on the word holding the label.
+__device__ inline uint32_t cc16_min(uint16_t *L, int i, uint32_t val)
+{
+    uint32_t *wp = (uint32_t *)L + (i >> 1);
+    const int sh = (i & 1) * 16;
+    uint32_t old = *(volatile uint32_t *)wp;
+    for (;;) {
+        uint32_t cur = (old >> sh) & 0xffffu;
+        if (cur <= val) return cur;
+        uint32_t nw = (old & ~(0xffffu << sh)) | (val << sh);
+        uint32_t prev = atomicCAS(wp, old, nw);
+        if (prev == old) return cur;
+        old = prev;
+    }
+}
+__device__ inline int cc16_find(uint16_t *L, int i)
+{
+    volatile uint16_t *V = L;
+    for (;;) {
+        int p = V[i];
+        if (p == i) return i;
+        int g = V[p];
+        if (g == p) return p;
+        V[i] = (uint16_t)g;      // path halving (benign race: g is an ancestor of i)
+        i = g;
+    }
+}
+__device__ inline void cc16_unite(uint16_t *L, int a, int b)
+{
+    for (;;) {
+        a = cc16_find(L, a);
+        b = cc16_find(L, b);
+        if (a == b) return;
+        if (a > b) { int t = a; a = b; b = t; }
+        uint32_t old = cc16_min(L, b, (uint32_t)a);
+        if ((int)old == b) return;
+        b = (int)old;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_cc_label_lds(const uint8_t *__restrict__ mask, int32_t *__restrict__ labels, int h, int w)
+{
+    extern __shared__ __attribute__((aligned(16))) uint16_t L16[];
+    size_t b = blockIdx.x;
+    int P = h * w;
+    const uint8_t *m = mask + b * (size_t)P;
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
+        // start each pixel at the left end of a short horizontal run segment (cuts find chains)
+        uint16_t l = 0xffffu;
+        if (m[p]) {
+            int x = p % w, q = p;
+            for (int s = 0; s < 7 && x - s > 0 && m[q - 1]; s++) q--;
+            l = (uint16_t)q;
+        }
+        L16[p] = l;
+    }
+    if ((P & 1) && threadIdx.x == 0) L16[P] = 0xffffu;
+    __syncthreads();
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
+        if (!m[p]) continue;
+        int y = p / w, x = p - y * w;
+        if (x > 0 && m[p - 1]) cc16_unite(L16, p, p - 1);
+        if (y > 0) {
+            if (m[p - w]) cc16_unite(L16, p, p - w);
+            if (x > 0 && m[p - w - 1]) cc16_unite(L16, p, p - w - 1);
+            if (x < w - 1 && m[p - w + 1]) cc16_unite(L16, p, p - w + 1);
+        }
+    }
+    __syncthreads();
+    int32_t *out = labels + b * (size_t)P;
+    for (int p = threadIdx.x; p < P; p += blockDim.x) out[p] = m[p] ? cc16_find(L16, p) : -1;
+}
+
 void launch_cc_label(const uint8_t *mask, int32_t *labels, int B, int h, int w, hipStream_t st)
 {
+    int P = h * w;
+    if (P <= 65535 && (size_t)(P + 2) * 2 <= 150 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) { hipFuncSetAttribute((const void *)k_cc_label_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        hipLaunchKernelGGL(k_cc_label_lds, dim3(B), dim3(1024), (size_t)(P + 2) * 2, st, mask, labels, h, w);
+        return;
+    }
     hipLaunchKernelGGL(k_cc_label, dim3(B), dim3(1024), 0, st, mask, labels, h, w);
 }
 

@@ -14,7 +14,7 @@
 
 namespace vf {
 
-constexpr int TQ_CAP = 4096;                 // LDS queue capacity (entries)
+constexpr int TQ_CAP = 6144;                 // LDS queue capacity (entries)
 constexpr uint8_t T_KNOWN = 0, T_BAND = 1, T_INSIDE = 2, T_CHANGE = 3, T_SEED = 0x80;   // T_SEED: bit flag, initial band
 
 __device__ inline float ldc(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -26,44 +26,66 @@ __device__ inline uint8_t ldf(const uint8_t *f, int i)
 }
 __device__ inline void drain() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
+// Stable priority queue kept as a SORTED array in LDS (the structure of OpenCV's CvPriorityQueueFloat): FMM
+// pushes are nearly monotone in T, so an insertion shifts only the few trailing entries with a larger T
+// (found and moved by the 64 lanes at once) and lands AFTER every entry with T' <= T (FIFO among ties);
+// pop is the head.  [head, tail) slides up; it is moved back to 0 when the array end is reached.
 struct TQueue {
-    unsigned long long *key;   // (float bits of T >= 0) << 32 | seq
-    int *idx;
-    int n, cap;
-    unsigned int seq;
+    uint32_t *T;       // float bits of T (>= 0), ascending in [head, tail)
+    uint32_t *idx;
+    int head, tail, cap;
     int overflow;
 };
 
-__device__ inline void tq_push(TQueue &q, float T, int idx, int lane)
+__device__ inline void tq_push(TQueue &q, float Tf, int idx, int lane)
 {
-    if (q.n >= q.cap) { q.overflow = 1; return; }
-    if (lane == 0) {
-        q.key[q.n] = ((unsigned long long)__float_as_uint(T) << 32) | q.seq;
-        q.idx[q.n] = idx;
+    if (q.tail >= q.cap) {
+        if (q.head == 0) { q.overflow = 1; return; }
+        int n = q.tail - q.head;
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            int j = j0 + lane;
+            uint32_t tv = 0, iv = 0;
+            if (j < n) { tv = q.T[j + q.head]; iv = q.idx[j + q.head]; }
+            if (j < n) { q.T[j] = tv; q.idx[j] = iv; }
+        }
+        q.head = 0; q.tail = n;
     }
-    q.n++;
-    q.seq++;
+    const uint32_t tb = __float_as_uint(Tf);
+    int k = 0;
+    for (;;) {
+        int j = q.tail - 1 - k - lane;
+        bool in = j >= q.head;
+        uint32_t tv = in ? q.T[j] : 0u;
+        uint32_t iv = in ? q.idx[j] : 0u;
+        unsigned long long g = __ballot(in && tv > tb);
+        int c = (g == ~0ull) ? 64 : (int)(__ffsll((long long)~g) - 1);     // leading run of "greater" entries
+        if (lane < c) { q.T[j + 1] = tv; q.idx[j + 1] = iv; }
+        k += c;
+        if (c < 64) break;
+    }
+    if (lane == 0) { q.T[q.tail - k] = tb; q.idx[q.tail - k] = (uint32_t)idx; }
+    q.tail++;
 }
 
-// pop the entry with the smallest (T, seq); returns pixel index or -1 when empty (uniform)
+// pop the smallest (T, then oldest); -1 when empty (uniform)
 __device__ inline int tq_pop(TQueue &q, int lane)
 {
-    if (q.n == 0) return -1;
-    unsigned long long best = ~0ull;
-    int bslot = -1;
-    for (int j = lane; j < q.n; j += 64) {
-        unsigned long long k = q.key[j];
-        if (k < best) { best = k; bslot = j; }
-    }
-    unsigned long long m = wave_min_u64(best);
-    unsigned long long who = __ballot(best == m && bslot >= 0);
-    int leader = __ffsll((long long)who) - 1;
-    int slot = __shfl(bslot, leader, 64);
-    int idx = q.idx[slot];
-    int last = q.n - 1;
-    if (lane == 0 && slot != last) { q.key[slot] = q.key[last]; q.idx[slot] = q.idx[last]; }
-    q.n = last;
-    return idx;
+    (void)lane;
+    if (q.head == q.tail) return -1;
+    int idx = (int)q.idx[q.head];
+    q.head++;
+    return __builtin_amdgcn_readfirstlane(idx);
+}
+
+// full-wave float sum (DPP butterfly; result uniform)
+__device__ inline float dpp_sum_f32(float x)
+{
+    int v = __float_as_int(x);
+#define VF_ADD(ctrl, rm)                                                                          \
+    v = __float_as_int(__int_as_float(v) + __int_as_float(__builtin_amdgcn_update_dpp(0, v, ctrl, rm, 0xf, false)));
+    VF_ADD(0xB1, 0xf) VF_ADD(0x4E, 0xf) VF_ADD(0x141, 0xf) VF_ADD(0x140, 0xf) VF_ADD(0x142, 0xa) VF_ADD(0x143, 0xc)
+#undef VF_ADD
+    return __int_as_float(__builtin_amdgcn_readlane(v, 63));
 }
 
 template <bool LF>
@@ -93,7 +115,7 @@ __device__ inline float fmm_dist(const uint8_t *f, const float *t, int p, int ec
     float s = fmm_solve<LF>(f, t, p1, p2);
     float o = __shfl_xor(s, 1, 64); s = o < s ? o : s;
     o = __shfl_xor(s, 2, 64); s = o < s ? o : s;
-    return __shfl(s, 0, 64);
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(s)));
 }
 
 template <bool LF>
@@ -108,11 +130,11 @@ __global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const
     const uint8_t *bad = bad_all + b * (size_t)P;
     float *t = gT + b * (size_t)en;
     TQueue q;
-    q.key = (unsigned long long *)lds_raw;
-    q.idx = (int *)(lds_raw + (size_t)TQ_CAP * 8);
-    q.cap = TQ_CAP; q.n = 0; q.seq = 0; q.overflow = 0;
+    q.T = (uint32_t *)lds_raw;
+    q.idx = (uint32_t *)(lds_raw + (size_t)TQ_CAP * 4);
+    q.cap = TQ_CAP; q.head = q.tail = 0; q.overflow = 0;
     uint8_t *f, *fo;
-    if (LF) { f = lds_raw + (size_t)TQ_CAP * 12; fo = f + ((en + 15) & ~15); }
+    if (LF) { f = lds_raw + (size_t)TQ_CAP * 8; fo = f + ((en + 15) & ~15); }
     else { f = gflags + b * (size_t)en * 2; fo = f + en; }
 
     // ---- flags: f = INSIDE on the hole; band = 4-neighbour dilation minus hole; ring for the outside T field
@@ -121,13 +143,13 @@ __global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const
         int y = i / ec, x = i - y * ec;
         bool in = (y >= 1 && y <= h && x >= 1 && x <= w) && bad[(size_t)(y - 1) * w + (x - 1)];
         f[i] = in ? T_INSIDE : T_KNOWN;
-        t[i] = 1.0e6f;
         nbad += in;
     }
     nbad = wave_sum(nbad);
+    if (nbad == 0) return;
+    for (int i = lane; i < en; i += 64) t[i] = 1.0e6f;
     drain();
     __syncthreads();
-    if (nbad == 0) return;
     for (int i = lane; i < en; i += 64) {
         int y = i / ec, x = i - y * ec;
         bool interior = (y >= 1 && y <= h && x >= 1 && x <= w);
@@ -193,10 +215,10 @@ __global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const
                 float o = __shfl_xor(dist, 1, 64); dist = o < dist ? o : dist;
                 o = __shfl_xor(dist, 2, 64); dist = o < dist ? o : dist;
                 for (int k = 0; k < 4; k++) {
-                    bool okk = __shfl((int)ok, k * 4, 64) != 0;
+                    bool okk = __builtin_amdgcn_readlane((int)ok, k * 4) != 0;
                     if (!okk) continue;
-                    float dk = __shfl(dist, k * 4, 64);
-                    int pk = __shfl(pn, k * 4, 64);
+                    float dk = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(dist), k * 4));
+                    int pk = __builtin_amdgcn_readlane(pn, k * 4);
                     if (lane == 0) { t[pk] = dk; fo[pk] = T_BAND; }
                     tq_push(q, dk, pk, lane);
                 }
@@ -213,7 +235,7 @@ __global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const
     __syncthreads();
 
     // ---- pass 2: Telea march.  Seeds = band pixels (raster order), then the queue.
-    q.n = 0; q.seq = 0;
+    q.head = q.tail = 0;
     const int r2 = range * range;
     const int side = 2 * range + 1, nn = side * side;
     for (int phase = 0; phase < 2; phase++) {
@@ -259,7 +281,7 @@ __global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const
                     if (kd) gty = ku ? __fmul_rn(__fsub_rn(td, tu), 0.5f) : __fsub_rn(td, tc);
                     else gty = ku ? __fsub_rn(tc, tu) : 0.f;
                 }
-                double sIa = 0, sJx = 0, sJy = 0, sS = 0;
+                float sIa = 0, sJx = 0, sJy = 0, sS = 0;
                 for (int n0 = 0; n0 < nn; n0 += 64) {
                     int nidx = n0 + lane;
                     float cIa = 0.f, cJx = 0.f, cJy = 0.f, cS = 0.f;
@@ -294,12 +316,12 @@ __global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const
                             }
                         }
                     }
-                    sIa += wave_sum((double)cIa);
-                    sJx -= wave_sum((double)cJx);
-                    sJy -= wave_sum((double)cJy);
-                    sS += wave_sum((double)cS);
+                    sIa += dpp_sum_f32(cIa);
+                    sJx -= dpp_sum_f32(cJx);
+                    sJy -= dpp_sum_f32(cJy);
+                    sS += dpp_sum_f32(cS);
                 }
-                float Ia = (float)sIa, Jx = (float)sJx, Jy = (float)sJy, s = (float)(sS + 1.0e-20);
+                float Ia = sIa, Jx = sJx, Jy = sJy, s = sS + 1.0e-20f;
                 float val = (float)((double)__fdiv_rn(Ia, s) +
                                     (double)__fadd_rn(Jx, Jy) / (sqrt((double)__fadd_rn(__fmul_rn(Jx, Jx), __fmul_rn(Jy, Jy))) + (double)1.0e-20f));
                 if (lane == 0) { img[(size_t)(i - 1) * w + (j - 1)] = val; f[pi] = T_BAND; }
@@ -320,7 +342,7 @@ size_t inpaint_scratch_bytes_per_frame(int h, int w)
 static size_t telea_lds_bytes(int h, int w)
 {
     size_t en = (size_t)(h + 2) * (w + 2);
-    return (size_t)TQ_CAP * 12 + 2 * ((en + 15) & ~(size_t)15);
+    return (size_t)TQ_CAP * 8 + 2 * ((en + 15) & ~(size_t)15);
 }
 
 void launch_inpaint_telea(float *img, const uint8_t *bad, int range, void *scratch, int32_t *status, int B, int h, int w,
@@ -336,7 +358,7 @@ void launch_inpaint_telea(float *img, const uint8_t *bad, int range, void *scrat
         if (!attr_set) { hipFuncSetAttribute((const void *)k_telea<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
         hipLaunchKernelGGL(k_telea<true>, dim3(B), dim3(64), lds_full, st, img, bad, range, gflags, gT, status, h, w);
     } else {
-        hipLaunchKernelGGL(k_telea<false>, dim3(B), dim3(64), (size_t)TQ_CAP * 12, st, img, bad, range, gflags, gT, status, h, w);
+        hipLaunchKernelGGL(k_telea<false>, dim3(B), dim3(64), (size_t)TQ_CAP * 8, st, img, bad, range, gflags, gT, status, h, w);
     }
 }
 

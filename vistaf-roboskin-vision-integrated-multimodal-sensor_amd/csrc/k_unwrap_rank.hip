@@ -12,9 +12,15 @@
 //                 parent store, needs no bounds checks or divisions (the border is "outside"), reads the
 //                 8 neighbours with 8 lanes, and finds the frontier maximum with a packed b128 scan of
 //                 uint16 keys plus one DPP wave reduction.  Keys are unique: no tie handling.
+#include <cstdlib>
+#include <cstring>
 #include "kernels.hpp"
 
 namespace vf {
+
+bool unwrap_hot_supported(int h, int w);
+void launch_unwrap_flood_hot(const uint16_t *rank16, const int32_t *seed, const uint32_t *inv, int32_t *ppar, size_t gstride,
+                             int32_t *status, int B, int h, int w, hipStream_t st);
 
 constexpr int RK_T = 1024;
 
@@ -282,6 +288,14 @@ void launch_unwrap_ranked(const float *quality, const uint8_t *mask, uint32_t *g
     int EN = (h + 2) * (w + 2);
     int cap = ranked_cap(EN);
     hipLaunchKernelGGL(k_unwrap_rank, dim3(B), dim3(RK_T), 0, st, quality, mask, g0, g1, g2, g3, gstride, rank16, seed, h, w);
+    // growth loop: "hot" (sorted register list + rank bitmap, default) or "scan" (frontier array scan)
+    static int use_hot = -1;
+    if (use_hot < 0) { const char *e = getenv("VISTAF_FLOOD"); use_hot = (e && !strcmp(e, "scan")) ? 0 : 1; }
+    if (use_hot && unwrap_hot_supported(h, w)) {
+        // after the 8 sort passes the sorted (key, index) arrays are back in g0 / g1: g1[rank] = padded pixel index
+        launch_unwrap_flood_hot(rank16, seed, g1, ppar, gstride, status, B, h, w, st);
+        return;
+    }
     static bool attr_set = false;
     if (!attr_set) { hipFuncSetAttribute((const void *)k_unwrap_flood_ranked, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
     size_t lds = (size_t)((EN + 7) & ~7) * 2 + (size_t)cap * 4;

@@ -57,6 +57,12 @@ size_t inpaint_scratch_bytes_per_frame(int h, int w);
 void launch_inpaint_telea(float *img, const uint8_t *bad, int range, void *scratch, int32_t *status, int B, int h, int w,
                           hipStream_t st);
 
+// ---- k_inpaint_cl.hip (cluster-parallel front end; leaves oversized clusters in *bad_big_out) ----------
+size_t inpaint_cl_scratch_bytes_per_frame(int h, int w);
+bool inpaint_clusters_supported(int range);
+void launch_inpaint_clusters(float *img, const uint8_t *bad, int range, void *scratch, uint8_t **bad_big_out, int B, int h, int w,
+                             hipStream_t st);
+
 // ---- k_unwrap.hip -----------------------------------------------------------------------------
 size_t unwrap_scratch_bytes_per_frame(int h, int w);
 void launch_unwrap(const float *wrapped, const float *quality, const uint8_t *mask, float *unwrapped, int32_t *parent,
