@@ -110,10 +110,64 @@ __global__ void k_morph(const uint8_t *__restrict__ src, uint8_t *__restrict__ d
     dst[b * (size_t)h * w + p] = (uint8_t)v;
 }
 
+// Row-prefix variant for wide elements: inc[y][x] = number of set pixels in row y up to and including x, so
+// "any / all set in [x0, x1]" is two loads per element row instead of a scan of the span.
+__global__ __launch_bounds__(256) void k_row_prefix(const uint8_t *__restrict__ src, uint16_t *__restrict__ inc, int rows, int w)
+{
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const uint8_t *s = src + (size_t)row * w;
+    uint16_t *o = inc + (size_t)row * w;
+    const unsigned long long le_mask = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+    unsigned int run = 0;
+    for (int x0 = 0; x0 < w; x0 += 64) {
+        int x = x0 + lane;
+        bool on = x < w && s[x] != 0;
+        unsigned long long bm = __ballot(on);
+        if (x < w) o[x] = (uint16_t)(run + (unsigned int)__popcll(bm & le_mask));
+        run += (unsigned int)__popcll(bm);
+    }
+}
+
+__global__ void k_morph_prefix(const uint16_t *__restrict__ inc, uint8_t *__restrict__ dst, int h, int w, RowSpanSE se, int dilate,
+                               const uint8_t *__restrict__ and_static, const uint8_t *__restrict__ and_frame)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y;
+    size_t b = blockIdx.z;
+    if (x >= w) return;
+    const uint16_t *I = inc + b * (size_t)h * w;
+    int r = se.k / 2;
+    int v = dilate ? 0 : 1;
+    for (int i = 0; i < se.k; i++) {
+        int yy = y + i - r;
+        if (yy < 0 || yy >= h) continue;
+        int x0 = x + se.lo[i], x1 = x + se.hi[i];
+        if (x0 < 0) x0 = 0;
+        if (x1 > w - 1) x1 = w - 1;
+        if (x1 < x0) continue;
+        const uint16_t *row = I + (size_t)yy * w;
+        int cnt = (int)row[x1] - (x0 > 0 ? (int)row[x0 - 1] : 0);
+        if (dilate) { if (cnt > 0) { v = 1; break; } }
+        else { if (cnt != x1 - x0 + 1) { v = 0; break; } }
+    }
+    size_t p = (size_t)y * w + x;
+    if (and_static && !and_static[p]) v = 0;
+    if (and_frame && !and_frame[b * (size_t)h * w + p]) v = 0;
+    dst[b * (size_t)h * w + p] = (uint8_t)v;
+}
+
 void launch_morph(const uint8_t *src, uint8_t *dst, int B, int h, int w, const RowSpanSE &se, bool dilate,
-                  const uint8_t *and_static, const uint8_t *and_frame, hipStream_t st)
+                  const uint8_t *and_static, const uint8_t *and_frame, hipStream_t st, uint16_t *prefix_scratch)
 {
     dim3 grid((w + 255) / 256, h, B);
+    if (prefix_scratch && se.k >= 7 && w < 65536) {
+        int rows = B * h;
+        hipLaunchKernelGGL(k_row_prefix, dim3((rows + 3) / 4), dim3(256), 0, st, src, prefix_scratch, rows, w);
+        hipLaunchKernelGGL(k_morph_prefix, grid, dim3(256), 0, st, prefix_scratch, dst, h, w, se, dilate ? 1 : 0, and_static, and_frame);
+        return;
+    }
     hipLaunchKernelGGL(k_morph, grid, dim3(256), 0, st, src, dst, h, w, se, dilate ? 1 : 0, and_static, and_frame);
 }
 

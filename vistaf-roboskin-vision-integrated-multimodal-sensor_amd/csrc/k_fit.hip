@@ -12,39 +12,28 @@
 
 namespace vf {
 
+// compacted fit sample: (z, xn, yn) of every pixel with mask != 0 and finite z (deterministic raster order)
 struct FitCtx {
-    const float *z; const uint8_t *m;
-    int w; float cxf, cyf;      // (w-1)/2, (h-1)/2 as float32
+    const float4 *comp;
     int order;
     float coef[6];
     float med;                  // for the MAD pass
     int mode;                   // 0: key = r, 1: key = |r - med|
-    __device__ inline void basis(int p, float &xn, float &yn) const
+    __device__ inline float resid(const float4 s) const
     {
-        int y = p / w, x = p - y * w;
-        xn = __fdiv_rn(__fsub_rn((float)x, cxf), cxf);
-        yn = __fdiv_rn(__fsub_rn((float)y, cyf), cyf);
-    }
-    __device__ inline float resid(int p) const
-    {
-        float xn, yn;
-        basis(p, xn, yn);
-        float f = __fmul_rn(coef[0], xn);
-        f = fmaf(coef[1], yn, f);
+        float f = __fmul_rn(coef[0], s.y);
+        f = fmaf(coef[1], s.z, f);
         f = __fadd_rn(f, coef[2]);
         if (order >= 2) {
-            f = fmaf(coef[3], __fmul_rn(xn, xn), f);
-            f = fmaf(coef[4], __fmul_rn(xn, yn), f);
-            f = fmaf(coef[5], __fmul_rn(yn, yn), f);
+            f = fmaf(coef[3], __fmul_rn(s.y, s.y), f);
+            f = fmaf(coef[4], __fmul_rn(s.y, s.z), f);
+            f = fmaf(coef[5], __fmul_rn(s.z, s.z), f);
         }
-        return __fsub_rn(z[p], f);
+        return __fsub_rn(s.x, f);
     }
-    __device__ bool operator()(int p, uint32_t &key) const
+    __device__ bool operator()(int e, uint32_t &key) const
     {
-        if (!m[p]) return false;
-        float zz = z[p];
-        if (!finitef(zz)) return false;
-        float r = resid(p);
+        float r = resid(comp[e]);
         if (mode) r = fabsf(__fsub_rn(r, med));
         key = f2key(r);
         return true;
@@ -69,51 +58,74 @@ __device__ inline bool chol_solve(double *A, double *rhs, int n)
 
 __global__ __launch_bounds__(SEL_T) void k_robust_polyfit(const float *__restrict__ z_all, const uint8_t *__restrict__ mask_all, int order,
                                                           int iters, float c, int min_count, float *__restrict__ coef_out,
-                                                          float *__restrict__ resid_all, int h, int w)
+                                                          float *__restrict__ resid_all, float4 *__restrict__ comp_all, int h, int w)
 {
     __shared__ SelShared sh;
     __shared__ double s_red[16];
     __shared__ double s_sum[27];
     __shared__ float s_coef[6];
-    __shared__ int s_ok;
+    __shared__ uint32_t s_wcnt[16];
     const size_t b = blockIdx.x;
-    const int P = h * w, tid = threadIdx.x;
+    const int P = h * w, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int nc = order >= 2 ? 6 : 3;
-    FitCtx ctx;
-    ctx.z = z_all + b * (size_t)P; ctx.m = mask_all + b * (size_t)P; ctx.w = w;
-    ctx.cxf = (float)((w - 1) / 2.0); ctx.cyf = (float)((h - 1) / 2.0);
-    ctx.order = order; ctx.med = 0.f; ctx.mode = 0;
-    for (int i = 0; i < 6; i++) ctx.coef[i] = 0.f;
+    const float *z = z_all + b * (size_t)P;
+    const uint8_t *m = mask_all + b * (size_t)P;
+    float4 *comp = comp_all + b * (size_t)P;
+    const float cxf = (float)((w - 1) / 2.0), cyf = (float)((h - 1) / 2.0);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-    // count of fitted pixels (mask & isfinite(z))
-    int cnt = 0;
-    for (int p = tid; p < P; p += SEL_T) cnt += (ctx.m[p] && finitef(ctx.z[p]));
-    uint32_t n = block_sum<uint32_t>((uint32_t)cnt, sh.wsum);
+    // ---- compaction (wave `wid` owns the contiguous pixel range [p0, p1)): (z, xn, yn) of the fitted pixels
+    const int Lw = (((P + 15) / 16) + 63) & ~63;
+    const int p0 = min(P, wid * Lw), p1 = min(P, p0 + Lw);
+    uint32_t cw = 0;
+    for (int pb = p0; pb < p1; pb += 64) {
+        int p = pb + lane;
+        bool ok = p < p1 && m[p] && finitef(z[p]);
+        cw += (uint32_t)__popcll(__ballot(ok));
+    }
+    if (lane == 0) s_wcnt[wid] = cw;
     __syncthreads();
-    bool do_fit = (int)n >= min_count;
+    uint32_t off = 0, n = 0;
+    for (int i = 0; i < 16; i++) { uint32_t x = s_wcnt[i]; if (i < wid) off += x; n += x; }
+    const bool do_fit = (int)n >= min_count;
+    if (do_fit) {
+        for (int pb = p0; pb < p1; pb += 64) {
+            int p = pb + lane;
+            float zz = p < p1 ? z[p] : 0.f;
+            bool ok = p < p1 && m[p] && finitef(zz);
+            unsigned long long bm = __ballot(ok);
+            if (ok) {
+                int y = p / w, x = p - y * w;
+                float xn = __fdiv_rn(__fsub_rn((float)x, cxf), cxf), yn = __fdiv_rn(__fsub_rn((float)y, cyf), cyf);
+                comp[off + (uint32_t)__popcll(bm & lt_mask)] = make_float4(zz, xn, yn, 0.f);
+            }
+            off += (uint32_t)__popcll(bm);
+        }
+    }
+    __threadfence();
+    __syncthreads();
 
+    FitCtx ctx;
+    ctx.comp = comp; ctx.order = order; ctx.med = 0.f; ctx.mode = 0;
+    for (int i = 0; i < 6; i++) ctx.coef[i] = 0.f;
     float csig = 1.f;      // c * sigma of the previous iteration
-    float medr = 0.f;
     for (int it = 0; do_fit && it < iters; it++) {
-        // ---- weighted normal equations
+        // ---- weighted normal equations over the compacted samples
         double acc[27];
 #pragma unroll
         for (int i = 0; i < 27; i++) acc[i] = 0.0;
-        for (int p = tid; p < P; p += SEL_T) {
-            if (!ctx.m[p]) continue;
-            float zz = ctx.z[p];
-            if (!finitef(zz)) continue;
-            float xn, yn;
-            ctx.basis(p, xn, yn);
+#pragma unroll 2
+        for (int e = tid; e < (int)n; e += SEL_T) {
+            const float4 s = comp[e];
             float wt = 1.f;
             if (it > 0) {
-                float u = __fdiv_rn(ctx.resid(p), csig);
+                float u = __fdiv_rn(ctx.resid(s), csig);
                 wt = __fdiv_rn(1.0f, __fadd_rn(1.0f, __fmul_rn(u, u)));
             }
             float a[6];
-            a[0] = __fmul_rn(xn, wt); a[1] = __fmul_rn(yn, wt); a[2] = wt;
-            a[3] = __fmul_rn(__fmul_rn(xn, xn), wt); a[4] = __fmul_rn(__fmul_rn(xn, yn), wt); a[5] = __fmul_rn(__fmul_rn(yn, yn), wt);
-            double zw = (double)__fmul_rn(zz, wt);
+            a[0] = __fmul_rn(s.y, wt); a[1] = __fmul_rn(s.z, wt); a[2] = wt;
+            a[3] = __fmul_rn(__fmul_rn(s.y, s.y), wt); a[4] = __fmul_rn(__fmul_rn(s.y, s.z), wt); a[5] = __fmul_rn(__fmul_rn(s.z, s.z), wt);
+            double zw = (double)__fmul_rn(s.x, wt);
             int k = 0;
 #pragma unroll
             for (int i = 0; i < 6; i++) {
@@ -136,7 +148,6 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit(const float *__restric
             for (int i = 0; i < 6; i++) rhs[i] = s_sum[21 + i];
             bool ok = chol_solve(A, rhs, nc);
             for (int i = 0; i < 6; i++) s_coef[i] = (ok && i < nc) ? (float)rhs[i] : 0.f;
-            s_ok = ok;
         }
         __syncthreads();
         for (int i = 0; i < 6; i++) ctx.coef[i] = s_coef[i];
@@ -144,12 +155,12 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit(const float *__restric
         // ---- sigma = 1.4826 * (median |r - median r| + 1e-6)
         uint32_t nn, kmin, kmax;
         ctx.mode = 0;
-        block_minmax(ctx, P, sh, nn, kmin, kmax);
-        medr = block_median(ctx, P, sh, nn, kmin, kmax);
+        block_minmax(ctx, (int)n, sh, nn, kmin, kmax);
+        float medr = block_median(ctx, (int)n, sh, nn, kmin, kmax);
         __syncthreads();
         ctx.med = medr; ctx.mode = 1;
-        block_minmax(ctx, P, sh, nn, kmin, kmax);
-        float mad = block_median(ctx, P, sh, nn, kmin, kmax);
+        block_minmax(ctx, (int)n, sh, nn, kmin, kmax);
+        float mad = block_median(ctx, (int)n, sh, nn, kmin, kmax);
         __syncthreads();
         ctx.mode = 0;
         mad = __fadd_rn(mad, 1e-6f);
@@ -160,11 +171,11 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit(const float *__restric
     // residual plane: z - fit, fit evaluated as eval_poly2d does (shape_ftp.py:1093-1097, :1132-1135)
     float *out = resid_all + b * (size_t)P;
     for (int p = tid; p < P; p += SEL_T) {
-        float zz = ctx.z[p];
+        float zz = z[p];
         float fit = 0.f;
         if (do_fit) {
-            float xn, yn;
-            ctx.basis(p, xn, yn);
+            int y = p / w, x = p - y * w;
+            float xn = __fdiv_rn(__fsub_rn((float)x, cxf), cxf), yn = __fdiv_rn(__fsub_rn((float)y, cyf), cyf);
             fit = __fadd_rn(__fadd_rn(__fmul_rn(ctx.coef[0], xn), __fmul_rn(ctx.coef[1], yn)), ctx.coef[2]);
             if (order >= 2) {
                 fit = __fadd_rn(fit, __fmul_rn(__fmul_rn(ctx.coef[3], xn), xn));
@@ -178,9 +189,10 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit(const float *__restric
 
 // min_count: 200 upstream (:1103); 500 for the debug_ramp call (shape_ftp.py:1365)
 void launch_robust_polyfit(const float *z, const uint8_t *mask, int order, int iters, float c, int min_count, float *coef_out,
-                           float *resid_out, int B, int h, int w, hipStream_t st)
+                           float *resid_out, void *comp_scratch, int B, int h, int w, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_robust_polyfit, dim3(B), dim3(SEL_T), 0, st, z, mask, order, iters, c, min_count, coef_out, resid_out, h, w);
+    hipLaunchKernelGGL(k_robust_polyfit, dim3(B), dim3(SEL_T), 0, st, z, mask, order, iters, c, min_count, coef_out, resid_out,
+                       (float4 *)comp_scratch, h, w);
 }
 
 }  // namespace vf

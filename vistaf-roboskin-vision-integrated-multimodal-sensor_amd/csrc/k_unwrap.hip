@@ -118,16 +118,18 @@ __global__ __launch_bounds__(64) void k_unwrap_flood(const float *__restrict__ q
 }
 
 // Tree -> wrap counts -> unwrapped phase, one 1024-thread workgroup per frame.
-// inc[p] = the integer n with (w[p]-w[par]) + 2*pi*n in (-pi, pi]; pointer jumping doubles the hop
-// length each round ((par, inc) -> (par[par], inc + inc[par])) until every pixel points at the seed.
-// Words written by other threads of the workgroup are read with agent-scope relaxed atomic loads.
-__device__ inline int ld_i32(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// ppar_all (optional): parents in PADDED (h+2)x(w+2) index space as written by k_unwrap_flood_ranked;
+// Each pixel carries one 64-bit word (parent index | wrap-count increment relative to that parent), where
+// inc = the integer n with (w[p]-w[par]) + 2*pi*n in (-pi, pi].  Pointer jumping replaces
+// (par, inc) by (par[par], inc + inc[par]) IN PLACE and asynchronously: every word always states a true
+// relation "k[p] = k[par] + inc" (the k are fixed by the tree), and a parent's word is read with one 64-bit
+// load, so any interleaving is consistent; rounds repeat until every pixel points at the seed.
+// ppar_all (optional): parents in PADDED (h+2)x(w+2) index space as written by the ranked flood kernels;
 // they are converted here and stored to parent_all (the plane the parity tests read back).
+__device__ inline unsigned long long ld_u64c(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void st_u64c(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __global__ __launch_bounds__(1024) void k_unwrap_tree(const float *__restrict__ wrapped_all, int32_t *parent_all,
-                                                      const int32_t *__restrict__ ppar_all, size_t gstride, int32_t *parA_all,
-                                                      int32_t *incA_all, int32_t *parB_all, int32_t *incB_all,
+                                                      const int32_t *__restrict__ ppar_all, size_t gstride, unsigned long long *words_all,
                                                       float *__restrict__ unwrapped_all, int h, int w)
 {
     __shared__ int s_changed;
@@ -135,8 +137,7 @@ __global__ __launch_bounds__(1024) void k_unwrap_tree(const float *__restrict__ 
     const int P = h * w;
     const float *wrapped = wrapped_all + b * (size_t)P;
     int32_t *tree = parent_all + b * (size_t)P;
-    int32_t *pi = parA_all + b * gstride, *ii = incA_all + b * gstride;
-    int32_t *po = parB_all + b * gstride, *io = incB_all + b * gstride;
+    unsigned long long *word = words_all + b * gstride;
     const double twopi = 6.283185307179586476925286766559, pi_d = 3.14159265358979323846;
     for (int p = threadIdx.x; p < P; p += blockDim.x) {
         int par;
@@ -147,7 +148,6 @@ __global__ __launch_bounds__(1024) void k_unwrap_tree(const float *__restrict__ 
             par = pp < 0 ? -1 : (pp / W2 - 1) * w + (pp % W2 - 1);
             tree[p] = par;
         } else par = tree[p];
-        pi[p] = par;
         int v = 0;
         if (par >= 0 && par != p) {
             double d = (double)wrapped[p] - (double)wrapped[par];
@@ -157,37 +157,45 @@ __global__ __launch_bounds__(1024) void k_unwrap_tree(const float *__restrict__ 
             else if (dd > pi_d) k -= 1.0;
             v = (int)k;
         }
-        ii[p] = v;
+        word[p] = (unsigned long long)(uint32_t)par | ((unsigned long long)(uint32_t)v << 32);
     }
     __threadfence();
     __syncthreads();
-    for (int round = 0; round < 40; round++) {
+    for (int round = 0; round < 64; round++) {
         if (threadIdx.x == 0) s_changed = 0;
         __syncthreads();
         int changed = 0;
-        for (int p = threadIdx.x; p < P; p += blockDim.x) {
-            int par = ld_i32(pi + p);
-            int v = ld_i32(ii + p);
-            if (par >= 0) {
-                int pp = ld_i32(pi + par);
-                if (pp != par) { v += ld_i32(ii + par); par = pp; changed = 1; }
+        for (int p0 = threadIdx.x; p0 < P; p0 += 4 * blockDim.x) {
+            unsigned long long wv[4], wq[4];
+            int pp[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { pp[u] = p0 + u * blockDim.x; wv[u] = pp[u] < P ? ld_u64c(word + pp[u]) : ~0ull; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { int par = (int)(uint32_t)wv[u]; wq[u] = (par >= 0 && par != pp[u]) ? ld_u64c(word + par) : ~0ull; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                int par = (int)(uint32_t)wv[u];
+                if (par < 0 || par == pp[u]) continue;
+                int pq = (int)(uint32_t)wq[u];
+                if (pq != par && pq >= 0) {
+                    int v = (int)(uint32_t)(wv[u] >> 32) + (int)(uint32_t)(wq[u] >> 32);
+                    st_u64c(word + pp[u], (unsigned long long)(uint32_t)pq | ((unsigned long long)(uint32_t)v << 32));
+                    changed = 1;
+                }
             }
-            po[p] = par;
-            io[p] = v;
         }
         if (changed) s_changed = 1;
         __threadfence();
         __syncthreads();
-        int32_t *t = pi; pi = po; po = t;
-        t = ii; ii = io; io = t;
         int any = s_changed;
         __syncthreads();
         if (!any) break;
     }
     float *unwrapped = unwrapped_all + b * (size_t)P;
     for (int p = threadIdx.x; p < P; p += blockDim.x) {
+        unsigned long long wv = ld_u64c(word + p);
         float u = __uint_as_float(0x7fc00000u);
-        if (ld_i32(pi + p) >= 0) u = (float)((double)wrapped[p] + twopi * (double)ld_i32(ii + p));
+        if ((int)(uint32_t)wv >= 0) u = (float)((double)wrapped[p] + twopi * (double)(int)(uint32_t)(wv >> 32));
         unwrapped[p] = u;
     }
 }
@@ -239,8 +247,8 @@ void launch_unwrap(const float *wrapped, const float *quality, const uint8_t *ma
         hipLaunchKernelGGL(k_unwrap_flood<false>, dim3(B), dim3(64), 0, st, quality, mask, parent, gst, g0, g1, P, status, h, w);
     }
     if (ev_mid) hipEventRecord(ev_mid, st);
-    hipLaunchKernelGGL(k_unwrap_tree, dim3(B), dim3(1024), 0, st, wrapped, parent, ppar, EN, (int32_t *)g3, (int32_t *)g0, (int32_t *)g1,
-                       (int32_t *)g2, unwrapped, h, w);
+    // g0|g1 (2 x B*EN uint32, contiguous) hold the per-pixel 64-bit words; stride EN words per frame
+    hipLaunchKernelGGL(k_unwrap_tree, dim3(B), dim3(1024), 0, st, wrapped, parent, ppar, EN, (unsigned long long *)g0, unwrapped, h, w);
 }
 
 }  // namespace vf

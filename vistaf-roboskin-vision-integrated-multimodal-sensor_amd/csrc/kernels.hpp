@@ -19,7 +19,7 @@ void launch_sobel_mag(const float *img, float *grad, int B, int h, int w, hipStr
 void launch_bad_flags(const float *img, const float *grad, const uint8_t *valid, const float *thr_hi, const float *thr_g,
                       uint8_t *bad, int B, int P, hipStream_t st);
 void launch_morph(const uint8_t *src, uint8_t *dst, int B, int h, int w, const RowSpanSE &se, bool dilate,
-                  const uint8_t *and_static, const uint8_t *and_frame, hipStream_t st);
+                  const uint8_t *and_static, const uint8_t *and_frame, hipStream_t st, uint16_t *prefix_scratch = nullptr);
 void launch_gauss_rows(const float *src, float *dst, const float *kern, int ksize, int B, int h, int w, hipStream_t st);
 void launch_gauss_cols(const float *src, float *dst, const float *kern, int ksize, int B, int h, int w, hipStream_t st);
 void launch_illum_norm(const float *img, const float *blur, float *out, int B, int P, hipStream_t st);
@@ -70,7 +70,7 @@ void launch_unwrap(const float *wrapped, const float *quality, const uint8_t *ma
 
 // ---- k_fit.hip --------------------------------------------------------------------------------
 void launch_robust_polyfit(const float *z, const uint8_t *mask, int order, int iters, float c, int min_count, float *coef_out,
-                           float *resid_out, int B, int h, int w, hipStream_t st);
+                           float *resid_out, void *comp_scratch /* 16 bytes per pixel */, int B, int h, int w, hipStream_t st);
 
 // ---- k_post.hip -------------------------------------------------------------------------------
 struct PostParams {
