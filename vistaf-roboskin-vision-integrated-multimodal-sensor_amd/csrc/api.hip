@@ -14,6 +14,7 @@
 #include "kernels.hpp"
 
 using namespace vf;
+namespace vf { void telea_debug_dump(); }
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -27,10 +28,10 @@ namespace {
 
 struct GKern { float *d = nullptr; int k = 0; };
 
-enum Stage { ST_GRAY_BAD = 0, ST_INPAINT, ST_PREPROC, ST_DEMOD, ST_RELIABLE, ST_UNWRAP, ST_UNWRAP_TREE, ST_DETREND, ST_SMOOTH_FLIP, ST_COMPOSE, ST_MM_BLOB,
+enum Stage { ST_GRAY_BAD = 0, ST_INPAINT, ST_PREPROC, ST_DEMOD, ST_RELIABLE, ST_UNWRAP_RANK, ST_UNWRAP, ST_UNWRAP_TREE, ST_DETREND, ST_SMOOTH_FLIP, ST_COMPOSE, ST_MM_BLOB,
              ST_TAIL, ST_COUNT };
 const char *kStageNames[ST_COUNT] = {"gray+badpix", "inpaint (k_telea)", "illum+blur+apod+median", "pruned-dft demod", "reliable mask",
-                                     "unwrap flood (k_unwrap_flood)", "unwrap tree", "detrend (3x IRLS)", "smooth+flip", "frontier+compose", "mm+blob filter", "tail"};
+                                     "unwrap rank (k_unwrap_rank)", "unwrap flood (k_unwrap_flood_hot)", "unwrap tree", "detrend (3x IRLS)", "smooth+flip", "frontier+compose", "mm+blob filter", "tail"};
 
 int cv_round(double v) { return (int)std::nearbyint(v); }
 
@@ -560,9 +561,9 @@ int vistaf_ftp_predict_batch(vistaf_ftp_handle *hd, const void *d_frames, int fo
     launch_mark_empty(hd->rel_count, hd->status, B, st);
 
     // ---- unwrap (shape_ftp.py:1702)
-    if (timed) hipEventRecord(hd->ev[ST_UNWRAP], st);
+    if (timed) hipEventRecord(hd->ev[ST_UNWRAP_RANK], st);
     launch_unwrap(hd->wrapped, qual, hd->reliable, hd->unwrapped, hd->parent, hd->unwrap_scratch, hd->status, B, h, w, st,
-                  timed ? hd->ev[ST_UNWRAP_TREE] : nullptr);
+                  timed ? hd->ev[ST_UNWRAP_TREE] : nullptr, timed ? hd->ev[ST_UNWRAP] : nullptr);
 
     // ---- plane removal + two-pass detrend (shape_ftp.py:1706, :1716-1751)
     if (timed) hipEventRecord(hd->ev[ST_DETREND], st);
@@ -631,6 +632,7 @@ int vistaf_ftp_predict_batch(vistaf_ftp_handle *hd, const void *d_frames, int fo
         hipEventSynchronize(hd->ev[ST_COUNT]);
         for (int i = 0; i < ST_COUNT; i++) hipEventElapsedTime(&hd->stage_ms[i], hd->ev[i], hd->ev[i + 1]);
     }
+    if (getenv("VISTAF_TELEA_DBG")) { hipStreamSynchronize(st); telea_debug_dump(); }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VISTAF_E_HIP, std::string("launch: ") + hipGetErrorString(e));
     return 0;

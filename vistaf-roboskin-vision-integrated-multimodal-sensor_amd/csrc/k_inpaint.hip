@@ -10,6 +10,7 @@
 // Mutable per-frame state: flag planes (LDS when (h+2)*(w+2) fits, else global), T field and image in
 // global memory.  Global mutable words are read with agent-scope relaxed atomic loads (L2-served)
 // and every store is drained (workgroup fence) before the next dependent read.
+#include <cstdio>
 #include "kernels.hpp"
 
 namespace vf {
@@ -30,6 +31,9 @@ __device__ inline void drain() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workg
 // pushes are nearly monotone in T, so an insertion shifts only the few trailing entries with a larger T
 // (found and moved by the 64 lanes at once) and lands AFTER every entry with T' <= T (FIFO among ties);
 // pop is the head.  [head, tail) slides up; it is moved back to 0 when the array end is reached.
+__device__ unsigned long long g_telea_dbg[16];   // diagnostic: shader-clock stamps / pop counts of frame 0 (VISTAF_TELEA_DBG)
+#define TSTAMP(i) do { if (b == 0 && lane == 0) g_telea_dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+
 struct TQueue {
     uint32_t *T;       // float bits of T (>= 0), ascending in [head, tail)
     uint32_t *idx;
@@ -118,9 +122,42 @@ __device__ inline float fmm_dist(const uint8_t *f, const float *t, int p, int ec
     return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(s)));
 }
 
+// Parallel preparation (one thread per padded cell): Telea flags f (INSIDE on the hole), outside-pass flags fo
+// (ring = within Chebyshev `range` of the hole, seeds = 4-neighbour band), T = 1e6 / 0 on the band, hole count.
+__global__ void k_telea_prep(const uint8_t *__restrict__ bad_all, uint8_t *__restrict__ gflags, float *__restrict__ gT,
+                             int32_t *__restrict__ nbad_all, int range, int h, int w)
+{
+    const int er = h + 2, ec = w + 2, en = er * ec;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    size_t b = blockIdx.y;
+    if (i >= en) return;
+    const uint8_t *bad = bad_all + b * (size_t)h * w;
+    int y = i / ec, x = i - y * ec;
+    auto hole = [&](int yy, int xx) -> bool { return yy >= 1 && yy <= h && xx >= 1 && xx <= w && bad[(size_t)(yy - 1) * w + (xx - 1)] != 0; };
+    bool interior = (y >= 1 && y <= h && x >= 1 && x <= w);
+    bool in = hole(y, x);
+    uint8_t fv = in ? T_INSIDE : T_KNOWN, fov = T_KNOWN;
+    float tv = 1.0e6f;
+    if (interior && !in) {
+        bool band = hole(y, x - 1) || hole(y, x + 1) || hole(y - 1, x) || hole(y + 1, x);
+        if (band) { fov = T_KNOWN | T_SEED; tv = 0.f; }   // seeds: known, T = 0 (Heap->Add(band) / Out->Add(band))
+        else {
+            bool near = false;
+            for (int a = -range; a <= range && !near; a++)
+                for (int c = -range; c <= range; c++)
+                    if (hole(y + a, x + c)) { near = true; break; }
+            if (near) fov = T_INSIDE;
+        }
+    }
+    gflags[b * (size_t)en * 2 + i] = fv;
+    gflags[b * (size_t)en * 2 + en + i] = fov;
+    gT[b * (size_t)en + i] = tv;
+    if (in) atomicAdd(&nbad_all[b], 1);
+}
+
 template <bool LF>
 __global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const uint8_t *__restrict__ bad_all, int range,
-                                              uint8_t *gflags, float *gT, int32_t *status, int h, int w)
+                                              uint8_t *gflags, float *gT, const int32_t *__restrict__ nbad_all, int32_t *status, int h, int w)
 {
     extern __shared__ unsigned char lds_raw[];
     const int lane = threadIdx.x;
@@ -137,44 +174,22 @@ __global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const
     if (LF) { f = lds_raw + (size_t)TQ_CAP * 8; fo = f + ((en + 15) & ~15); }
     else { f = gflags + b * (size_t)en * 2; fo = f + en; }
 
-    // ---- flags: f = INSIDE on the hole; band = 4-neighbour dilation minus hole; ring for the outside T field
-    int nbad = 0;
-    for (int i = lane; i < en; i += 64) {
-        int y = i / ec, x = i - y * ec;
-        bool in = (y >= 1 && y <= h && x >= 1 && x <= w) && bad[(size_t)(y - 1) * w + (x - 1)];
-        f[i] = in ? T_INSIDE : T_KNOWN;
-        nbad += in;
-    }
-    nbad = wave_sum(nbad);
+    TSTAMP(0);
+    TSTAMP(0);
+    // ---- flags and the initial T field were prepared by k_telea_prep (all CUs); stage the flag planes into LDS
+    const int nbad = nbad_all[b];
     if (nbad == 0) return;
-    for (int i = lane; i < en; i += 64) t[i] = 1.0e6f;
-    drain();
-    __syncthreads();
-    for (int i = lane; i < en; i += 64) {
-        int y = i / ec, x = i - y * ec;
-        bool interior = (y >= 1 && y <= h && x >= 1 && x <= w);
-        uint8_t v = T_KNOWN;
-        if (interior && ldf<LF>(f, i) != T_INSIDE) {
-            bool near = false;
-            for (int a = -range; a <= range && !near; a++) {
-                int yy = y + a; if (yy < 0 || yy >= er) continue;
-                for (int c = -range; c <= range; c++) {
-                    int xx = x + c; if (xx < 0 || xx >= ec) continue;
-                    if (ldf<LF>(f, yy * ec + xx) == T_INSIDE) { near = true; break; }
-                }
-            }
-            bool band = ldf<LF>(f, i - 1) == T_INSIDE || ldf<LF>(f, i + 1) == T_INSIDE || ldf<LF>(f, i - ec) == T_INSIDE ||
-                        ldf<LF>(f, i + ec) == T_INSIDE;
-            if (band) { v = T_KNOWN | T_SEED; t[i] = 0.f; }   // seeds: known, T = 0 (Heap->Add(band) / Out->Add(band))
-            else if (near) v = T_INSIDE;
-        }
-        fo[i] = v;
+    if (LF) {
+        const uint8_t *gsrc = gflags + b * (size_t)en * 2;
+        for (int i = lane; i < en; i += 64) { f[i] = gsrc[i]; fo[i] = gsrc[en + i]; }
+        __syncthreads();
     }
-    drain();
-    __syncthreads();
 
+    TSTAMP(1);
+    unsigned long long npop1 = 0, npop2 = 0;
     // ---- pass 1: outside T field.  Seeds (band, T = 0) pop first, in raster order.
     for (int phase = 0; phase < 2; phase++) {
+        if (phase == 1) TSTAMP(2);
         int base = 0;
         unsigned long long pend = 0;
         for (;;) {
@@ -194,6 +209,7 @@ __global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const
                 p = tq_pop(q, lane);
                 if (p < 0) break;
             }
+            npop1++;
             if (lane == 0) fo[p] = (uint8_t)(T_CHANGE | (phase == 0 ? T_SEED : 0));
             // the four 4-neighbours are independent of one another in this pass: lanes 0..15 = 4 pixels x 4 quadrants
             int nb = lane >> 2;
@@ -228,17 +244,28 @@ __global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const
     }
     drain();
     __syncthreads();
+    TSTAMP(3);
     // negate T where the outside pass ran (CHANGE), seeds keep T = 0
     for (int i = lane; i < en; i += 64)
         if ((ldf<LF>(fo, i) & 0x7f) == T_CHANGE) { float v = ldc(t + i); t[i] = -v; }
     drain();
     __syncthreads();
 
+    TSTAMP(4);
     // ---- pass 2: Telea march.  Seeds = band pixels (raster order), then the queue.
     q.head = q.tail = 0;
     const int r2 = range * range;
+    // 1 / |r|^3 of this lane's neighbour offset (first two 64-neighbour chunks), hoisted out of the march
+    float pre_dstw[2];
+    for (int c2 = 0; c2 < 2; c2++) {
+        int nidx = c2 * 64 + lane, sd = 2 * range + 1;
+        float ry = (float)(range - nidx / sd), rx = (float)(range - nidx % sd);
+        float len2 = __fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry));
+        pre_dstw[c2] = len2 > 0.f ? (float)(1. / (double)__fmul_rn(len2, __fsqrt_rn(len2))) : 0.f;
+    }
     const int side = 2 * range + 1, nn = side * side;
     for (int phase = 0; phase < 2; phase++) {
+        if (phase == 1) TSTAMP(5);
         int base = 0;
         unsigned long long pend = 0;
         for (;;) {
@@ -258,6 +285,7 @@ __global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const
                 p = tq_pop(q, lane);
                 if (p < 0) break;
             }
+            npop2++;
             if (phase == 1 && lane == 0) f[p] = T_KNOWN;
             if (LF) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); else drain();
             for (int qn = 0; qn < 4; qn++) {
@@ -294,11 +322,11 @@ __global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const
                                 int lm = l - 1 + (l == 1), lp = l - 1 - (l == ec - 2);
                                 float ry = (float)(i - k), rx = (float)(j - l);
                                 float len2 = __fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry));
-                                float dstw = (float)(1. / (double)__fmul_rn(len2, __fsqrt_rn(len2)));
+                                float dstw = n0 == 0 ? pre_dstw[0] : (n0 == 64 ? pre_dstw[1] : (float)(1. / (double)__fmul_rn(len2, __fsqrt_rn(len2))));
                                 float tk = (pk == pi) ? tc : ldc(t + pk);
                                 float lev = (float)(1. / (1 + fabs((double)__fsub_rn(tk, tc))));
                                 float dir = __fadd_rn(__fmul_rn(rx, gtx), __fmul_rn(ry, gty));
-                                if (fabs((double)dir) <= 0.01) dir = 0.000001f;
+                                if (fabsf(dir) <= 0.01f) dir = 0.000001f;   // float(0.01) < 0.01: same set of floats as the double compare
                                 float wgt = fabsf(__fmul_rn(__fmul_rn(dstw, lev), dir));
                                 float gix, giy;
                                 bool kr = ldf<LF>(f, pk + 1) != T_INSIDE, kl = ldf<LF>(f, pk - 1) != T_INSIDE;
@@ -330,13 +358,23 @@ __global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const
             }
         }
     }
+    TSTAMP(6);
+    if (b == 0 && lane == 0) { g_telea_dbg[8] = npop1; g_telea_dbg[9] = npop2; g_telea_dbg[10] = (unsigned long long)nbad; }
     if (q.overflow && lane == 0) status[b] = 2;
+}
+
+void telea_debug_dump()
+{
+    unsigned long long h[16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_telea_dbg), sizeof(h)) != hipSuccess) return;
+    printf("[telea dbg] cycles: init %llu | pass1 seeds %llu | pass1 queue %llu | negate %llu | pass2 seeds %llu | pass2 queue %llu | pops %llu / %llu | bad %llu\n",
+           h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[8], h[9], h[10]);
 }
 
 size_t inpaint_scratch_bytes_per_frame(int h, int w)
 {
     size_t en = (size_t)(h + 2) * (w + 2);
-    return en * sizeof(float) + 2 * en + 64;
+    return en * sizeof(float) + 2 * en + 64 + 8;
 }
 
 static size_t telea_lds_bytes(int h, int w)
@@ -352,13 +390,17 @@ void launch_inpaint_telea(float *img, const uint8_t *bad, int range, void *scrat
     // scratch layout: [B*en floats T][B*2*en bytes flags]
     float *gT = (float *)scratch;
     uint8_t *gflags = (uint8_t *)scratch + (size_t)B * en * sizeof(float);
+    int32_t *nbad = (int32_t *)((uint8_t *)scratch + (size_t)B * en * sizeof(float) + (size_t)B * en * 2);
+    nbad = (int32_t *)(((uintptr_t)nbad + 63) & ~(uintptr_t)63);
+    hipMemsetAsync(nbad, 0, sizeof(int32_t) * B, st);
+    hipLaunchKernelGGL(k_telea_prep, dim3((unsigned)((en + 255) / 256), B), dim3(256), 0, st, bad, gflags, gT, nbad, range, h, w);
     size_t lds_full = telea_lds_bytes(h, w);
     if (lds_full <= 160 * 1024) {
         static bool attr_set = false;
         if (!attr_set) { hipFuncSetAttribute((const void *)k_telea<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-        hipLaunchKernelGGL(k_telea<true>, dim3(B), dim3(64), lds_full, st, img, bad, range, gflags, gT, status, h, w);
+        hipLaunchKernelGGL(k_telea<true>, dim3(B), dim3(64), lds_full, st, img, bad, range, gflags, gT, nbad, status, h, w);
     } else {
-        hipLaunchKernelGGL(k_telea<false>, dim3(B), dim3(64), (size_t)TQ_CAP * 8, st, img, bad, range, gflags, gT, status, h, w);
+        hipLaunchKernelGGL(k_telea<false>, dim3(B), dim3(64), (size_t)TQ_CAP * 8, st, img, bad, range, gflags, gT, nbad, status, h, w);
     }
 }
 

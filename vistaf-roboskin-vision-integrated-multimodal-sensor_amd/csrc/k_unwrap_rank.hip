@@ -283,11 +283,12 @@ bool unwrap_ranked_supported(int h, int w)
 // g0..g3: uint32 planes of gstride elements per frame (sort ping-pong); ppar: int32 plane of gstride elements
 void launch_unwrap_ranked(const float *quality, const uint8_t *mask, uint32_t *g0, uint32_t *g1, uint32_t *g2, uint32_t *g3,
                           int32_t *ppar, size_t gstride, uint16_t *rank16, int32_t *seed, int32_t *status, int B, int h, int w,
-                          hipStream_t st)
+                          hipStream_t st, hipEvent_t ev_flood)
 {
     int EN = (h + 2) * (w + 2);
     int cap = ranked_cap(EN);
     hipLaunchKernelGGL(k_unwrap_rank, dim3(B), dim3(RK_T), 0, st, quality, mask, g0, g1, g2, g3, gstride, rank16, seed, h, w);
+    if (ev_flood) hipEventRecord(ev_flood, st);
     // growth loop: "hot" (sorted register list + rank bitmap, default) or "scan" (frontier array scan)
     static int use_hot = -1;
     if (use_hot < 0) { const char *e = getenv("VISTAF_FLOOD"); use_hot = (e && !strcmp(e, "scan")) ? 0 : 1; }

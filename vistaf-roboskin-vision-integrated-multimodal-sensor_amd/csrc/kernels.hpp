@@ -66,7 +66,8 @@ void launch_inpaint_clusters(float *img, const uint8_t *bad, int range, void *sc
 // ---- k_unwrap.hip -----------------------------------------------------------------------------
 size_t unwrap_scratch_bytes_per_frame(int h, int w);
 void launch_unwrap(const float *wrapped, const float *quality, const uint8_t *mask, float *unwrapped, int32_t *parent,
-                   void *scratch, int32_t *status, int B, int h, int w, hipStream_t st, hipEvent_t ev_mid);
+                   void *scratch, int32_t *status, int B, int h, int w, hipStream_t st, hipEvent_t ev_mid,
+                   hipEvent_t ev_flood = nullptr);
 
 // ---- k_fit.hip --------------------------------------------------------------------------------
 void launch_robust_polyfit(const float *z, const uint8_t *mask, int order, int iters, float c, int min_count, float *coef_out,
