@@ -22,11 +22,12 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 224
     nb = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     mode = sys.argv[3] if len(sys.argv) > 3 else "scaled"
+    config = int(sys.argv[4]) if len(sys.argv) > 4 else 3
     cfg = pkg.FtpConfig.scaled(n) if mode == "scaled" else pkg.FtpConfig.as_shipped()
     cal, neg = pkg.load_calibration(os.path.join(G, "calibration_phase_to_height.json"))
     fm = pkg.load_force_calibration(os.path.join(G, "calibration_height_to_force.json"))["best_model"]
-    ref = pkg.synth.reference_frame(n)
-    frames = pkg.synth.deformed_batch(n, 0, nb)
+    ref = pkg.synth.reference_frame(n, config=config)
+    frames = pkg.synth.deformed_batch(n, 0, nb, config=config)
     cx, cy, r = pkg.synth.roi_circle(n)
     t0 = time.time()
     sensor = pkg.FtpSensor(ref, (cx, cy, r), cfg, cal, neg, fm, max_batch=nb)

@@ -34,6 +34,8 @@ __device__ inline void drain() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workg
 __device__ unsigned long long g_telea_dbg[16];   // diagnostic: shader-clock stamps / pop counts of frame 0 (VISTAF_TELEA_DBG)
 #define TSTAMP(i) do { if (b == 0 && lane == 0) g_telea_dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
 
+__device__ inline uint32_t ldq(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 struct TQueue {
     uint32_t *T;       // float bits of T (>= 0), ascending in [head, tail)
     uint32_t *idx;
@@ -41,16 +43,20 @@ struct TQueue {
     int overflow;
 };
 
+template <bool LQ>
 __device__ inline void tq_push(TQueue &q, float Tf, int idx, int lane)
 {
+    if (!LQ) drain();
     if (q.tail >= q.cap) {
         if (q.head == 0) { q.overflow = 1; return; }
         int n = q.tail - q.head;
         for (int j0 = 0; j0 < n; j0 += 64) {
             int j = j0 + lane;
             uint32_t tv = 0, iv = 0;
-            if (j < n) { tv = q.T[j + q.head]; iv = q.idx[j + q.head]; }
+            if (j < n) { tv = LQ ? q.T[j + q.head] : ldq(q.T + j + q.head); iv = LQ ? q.idx[j + q.head] : ldq(q.idx + j + q.head); }
+            if (!LQ) drain();
             if (j < n) { q.T[j] = tv; q.idx[j] = iv; }
+            if (!LQ) drain();
         }
         q.head = 0; q.tail = n;
     }
@@ -59,11 +65,13 @@ __device__ inline void tq_push(TQueue &q, float Tf, int idx, int lane)
     for (;;) {
         int j = q.tail - 1 - k - lane;
         bool in = j >= q.head;
-        uint32_t tv = in ? q.T[j] : 0u;
-        uint32_t iv = in ? q.idx[j] : 0u;
+        uint32_t tv = in ? (LQ ? q.T[j] : ldq(q.T + j)) : 0u;
+        uint32_t iv = in ? (LQ ? q.idx[j] : ldq(q.idx + j)) : 0u;
         unsigned long long g = __ballot(in && tv > tb);
         int c = (g == ~0ull) ? 64 : (int)(__ffsll((long long)~g) - 1);     // leading run of "greater" entries
+        if (!LQ) drain();
         if (lane < c) { q.T[j + 1] = tv; q.idx[j + 1] = iv; }
+        if (!LQ) drain();
         k += c;
         if (c < 64) break;
     }
@@ -72,11 +80,13 @@ __device__ inline void tq_push(TQueue &q, float Tf, int idx, int lane)
 }
 
 // pop the smallest (T, then oldest); -1 when empty (uniform)
+template <bool LQ>
 __device__ inline int tq_pop(TQueue &q, int lane)
 {
     (void)lane;
     if (q.head == q.tail) return -1;
-    int idx = (int)q.idx[q.head];
+    if (!LQ) drain();
+    int idx = (int)(LQ ? q.idx[q.head] : ldq(q.idx + q.head));
     q.head++;
     return __builtin_amdgcn_readfirstlane(idx);
 }
@@ -157,7 +167,8 @@ __global__ void k_telea_prep(const uint8_t *__restrict__ bad_all, uint8_t *__res
 
 template <bool LF>
 __global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const uint8_t *__restrict__ bad_all, int range,
-                                              uint8_t *gflags, float *gT, const int32_t *__restrict__ nbad_all, int32_t *status, int h, int w)
+                                              uint8_t *gflags, float *gT, uint32_t *gqueue, const int32_t *__restrict__ nbad_all, int32_t *status, int h,
+                                              int w)
 {
     extern __shared__ unsigned char lds_raw[];
     const int lane = threadIdx.x;
@@ -167,9 +178,9 @@ __global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const
     const uint8_t *bad = bad_all + b * (size_t)P;
     float *t = gT + b * (size_t)en;
     TQueue q;
-    q.T = (uint32_t *)lds_raw;
-    q.idx = (uint32_t *)(lds_raw + (size_t)TQ_CAP * 4);
-    q.cap = TQ_CAP; q.head = q.tail = 0; q.overflow = 0;
+    if (LF) { q.T = (uint32_t *)lds_raw; q.idx = (uint32_t *)(lds_raw + (size_t)TQ_CAP * 4); q.cap = TQ_CAP; }
+    else { q.T = gqueue + b * (size_t)en * 2; q.idx = q.T + en; q.cap = en; }   // large frames: queue in global memory
+    q.head = q.tail = 0; q.overflow = 0;
     uint8_t *f, *fo;
     if (LF) { f = lds_raw + (size_t)TQ_CAP * 8; fo = f + ((en + 15) & ~15); }
     else { f = gflags + b * (size_t)en * 2; fo = f + en; }
@@ -206,7 +217,7 @@ __global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const
                 p = base + l;
                 if (!pend) base += 64;
             } else {
-                p = tq_pop(q, lane);
+                p = tq_pop<LF>(q, lane);
                 if (p < 0) break;
             }
             npop1++;
@@ -236,7 +247,7 @@ __global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const
                     float dk = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(dist), k * 4));
                     int pk = __builtin_amdgcn_readlane(pn, k * 4);
                     if (lane == 0) { t[pk] = dk; fo[pk] = T_BAND; }
-                    tq_push(q, dk, pk, lane);
+                    tq_push<LF>(q, dk, pk, lane);
                 }
             }
             if (LF) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -282,7 +293,7 @@ __global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const
                 p = base + l;
                 if (!pend) base += 64;
             } else {
-                p = tq_pop(q, lane);
+                p = tq_pop<LF>(q, lane);
                 if (p < 0) break;
             }
             npop2++;
@@ -353,7 +364,7 @@ __global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const
                 float val = (float)((double)__fdiv_rn(Ia, s) +
                                     (double)__fadd_rn(Jx, Jy) / (sqrt((double)__fadd_rn(__fmul_rn(Jx, Jx), __fmul_rn(Jy, Jy))) + (double)1.0e-20f));
                 if (lane == 0) { img[(size_t)(i - 1) * w + (j - 1)] = val; f[pi] = T_BAND; }
-                tq_push(q, dist, pi, lane);
+                tq_push<LF>(q, dist, pi, lane);
                 if (LF) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             }
         }
@@ -374,7 +385,7 @@ void telea_debug_dump()
 size_t inpaint_scratch_bytes_per_frame(int h, int w)
 {
     size_t en = (size_t)(h + 2) * (w + 2);
-    return en * sizeof(float) + 2 * en + 64 + 8;
+    return en * sizeof(float) + 2 * en + 8 * en /*global queue (large frames)*/ + 64 + 8 + 256;
 }
 
 static size_t telea_lds_bytes(int h, int w)
@@ -390,17 +401,17 @@ void launch_inpaint_telea(float *img, const uint8_t *bad, int range, void *scrat
     // scratch layout: [B*en floats T][B*2*en bytes flags]
     float *gT = (float *)scratch;
     uint8_t *gflags = (uint8_t *)scratch + (size_t)B * en * sizeof(float);
-    int32_t *nbad = (int32_t *)((uint8_t *)scratch + (size_t)B * en * sizeof(float) + (size_t)B * en * 2);
-    nbad = (int32_t *)(((uintptr_t)nbad + 63) & ~(uintptr_t)63);
+    uint32_t *gqueue = (uint32_t *)((((uintptr_t)scratch + (size_t)B * en * sizeof(float) + (size_t)B * en * 2) + 255) & ~(uintptr_t)255);
+    int32_t *nbad = (int32_t *)(gqueue + (size_t)B * en * 2);
     hipMemsetAsync(nbad, 0, sizeof(int32_t) * B, st);
     hipLaunchKernelGGL(k_telea_prep, dim3((unsigned)((en + 255) / 256), B), dim3(256), 0, st, bad, gflags, gT, nbad, range, h, w);
     size_t lds_full = telea_lds_bytes(h, w);
     if (lds_full <= 160 * 1024) {
         static bool attr_set = false;
         if (!attr_set) { hipFuncSetAttribute((const void *)k_telea<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-        hipLaunchKernelGGL(k_telea<true>, dim3(B), dim3(64), lds_full, st, img, bad, range, gflags, gT, nbad, status, h, w);
+        hipLaunchKernelGGL(k_telea<true>, dim3(B), dim3(64), lds_full, st, img, bad, range, gflags, gT, gqueue, nbad, status, h, w);
     } else {
-        hipLaunchKernelGGL(k_telea<false>, dim3(B), dim3(64), (size_t)TQ_CAP * 8, st, img, bad, range, gflags, gT, nbad, status, h, w);
+        hipLaunchKernelGGL(k_telea<false>, dim3(B), dim3(64), 0, st, img, bad, range, gflags, gT, gqueue, nbad, status, h, w);
     }
 }
 
