@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--constants", choices=["scaled", "shipped"], default="scaled")
+    ap.add_argument("--inflight", type=int, default=1, help="independent sessions/streams whose steps may overlap (1 = strictly serial steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     args = ap.parse_args()
@@ -94,18 +95,31 @@ def main():
     frames = torch.from_numpy(frames_u8).to(dev)
     frames = frames[..., None].expand(-1, -1, -1, 3).to(torch.float16).contiguous()   # [B, n, n, 3] fp16
     ref3 = torch.from_numpy(ref).to(dev)[..., None].expand(-1, -1, 3).to(torch.float16).contiguous()
-    sensor = pkg.FtpSensor(ref3, pkg.synth.roi_circle(n), cfg, cal, neg, fm, max_batch=B, device=dev)
-    out = sensor.predict_batch(frames)
+    sensors = [pkg.FtpSensor(ref3, pkg.synth.roi_circle(n), cfg, cal, neg, fm, max_batch=B, device=dev) for _ in range(max(1, args.inflight))]
+    streams = [torch.cuda.Stream(device=dev) for _ in sensors] if len(sensors) > 1 else [None]
+    sensor = sensors[0]
+    outs = [s_.predict_batch(frames) for s_ in sensors]
+    out = outs[0]
+    torch.cuda.synchronize(dev)
+    step_no = [0]
     gathered_h = gathered_s = None
     if world > 1:
         gathered_h = torch.empty((world * B, n, n), dtype=torch.float32, device=dev)
         gathered_s = torch.empty((world * B, out["scalars"].shape[1]), dtype=torch.float64, device=dev)
 
     def step():
-        sensor.predict_batch(frames, out)
+        k = step_no[0] % len(sensors)
+        step_no[0] += 1
+        if streams[k] is None:
+            sensors[k].predict_batch(frames, outs[k])
+        else:
+            with torch.cuda.stream(streams[k]):
+                sensors[k].predict_batch(frames, outs[k])
         if world > 1:
-            dist.all_gather_into_tensor(gathered_h, out["height_map_mm"])
-            dist.all_gather_into_tensor(gathered_s, out["scalars"])
+            if streams[k] is not None:
+                torch.cuda.current_stream(dev).wait_stream(streams[k])
+            dist.all_gather_into_tensor(gathered_h, outs[k]["height_map_mm"])
+            dist.all_gather_into_tensor(gathered_s, outs[k]["scalars"])
 
     for _ in range(args.warmup):
         step()
@@ -169,7 +183,7 @@ def main():
                             f"full FTP path (inpaint, demod, unwrap, detrend, compose, force tail), constants {args.constants}-{n}; "
                             f"inputs resident in HBM" + ("; one RCCL all-gather of maps+scalars per step" if world > 1 else ""),
                 "global_batch": world * B, "frame": [n, n, 3], "input_dtype": "fp16", "constants": args.constants,
-                "parallelism": f"dp{world}", "frames_with_nonzero_status": status_bad,
+                "parallelism": f"dp{world}", "inflight_batches": len(sensors), "frames_with_nonzero_status": status_bad,
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
