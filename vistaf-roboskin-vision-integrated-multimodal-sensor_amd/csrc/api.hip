@@ -14,7 +14,7 @@
 #include "kernels.hpp"
 
 using namespace vf;
-namespace vf { void telea_debug_dump(); }
+namespace vf { void telea_debug_dump(); void telea_window_debug_dump(int B); }
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -67,7 +67,7 @@ struct vistaf_ftp_handle {
     int32_t *labels, *area, *rowdist, *parent;
     unsigned int *peak_bits;
     uint16_t *morph_pre;
-    void *inpaint_scratch, *inpaint_cl_scratch, *unwrap_scratch, *fit_scratch;
+    void *inpaint_scratch, *inpaint_cl_scratch, *inpaint_win_scratch, *unwrap_scratch, *fit_scratch;
     // small per-frame arrays
     float *thr_hi, *thr_g, *mu, *amp_thr, *thr3, *thr_used, *bg_med, *core_thr, *core_med, *coef;
     int *cnt_a, *cnt_valid, *rel_count, *contact_count, *bg_count, *bad_count, *flipped;
@@ -169,14 +169,18 @@ void preprocess(vistaf_ftp_handle *hd, const void *frames, int format, int B, hi
         {
             int range = std::min(100, std::max(1, cv_round((double)c.bad_inpaint_radius)));   // cv::inpaint clamps the radius
             const uint8_t *seq_mask = hd->bad1;
-            static int use_cl = -1;   // cluster-parallel front end: VISTAF_INPAINT=cluster (off by default: see DESIGN.md)
-            if (use_cl < 0) { const char *ev = getenv("VISTAF_INPAINT"); use_cl = (ev && !strcmp(ev, "cluster")) ? 1 : 0; }
-            if (use_cl && inpaint_clusters_supported(range)) {
+            const int32_t *only = nullptr;
+            // default: LDS window kernel, whole-frame kernel for the frames it hands back.
+            // VISTAF_INPAINT=seq: whole-frame kernel only; =cluster: cluster-parallel front end
+            static int mode = -1;
+            if (mode < 0) { const char *ev = getenv("VISTAF_INPAINT"); mode = (ev && !strcmp(ev, "cluster")) ? 2 : (ev && !strcmp(ev, "seq")) ? 1 : 0; }
+            if (mode == 0) only = launch_inpaint_window(hd->img, hd->bad1, range, hd->inpaint_win_scratch, B, h, w, st);
+            if (mode == 2 && inpaint_clusters_supported(range)) {
                 uint8_t *bad_big = nullptr;
                 launch_inpaint_clusters(hd->img, hd->bad1, range, hd->inpaint_cl_scratch, &bad_big, B, h, w, st);
                 seq_mask = bad_big;     // only clusters too large for an LDS window remain for the sequential kernel
             }
-            launch_inpaint_telea(hd->img, seq_mask, range, hd->inpaint_scratch, hd->status, B, h, w, st);
+            launch_inpaint_telea(hd->img, seq_mask, range, hd->inpaint_scratch, hd->status, only, B, h, w, st);
         }
     } else if (timed) hipEventRecord(hd->ev[ST_INPAINT], st);
     if (timed) hipEventRecord(hd->ev[ST_PREPROC], st);
@@ -354,6 +358,7 @@ int vistaf_ftp_create(const vistaf_ftp_config *cfg, int h, int w, int cx, int cy
         void *p = nullptr;
         TRY(dalloc(hd, (uint8_t **)&p, inpaint_scratch_bytes_per_frame(h, w) * max_batch)); hd->inpaint_scratch = p;
         TRY(dalloc(hd, (uint8_t **)&p, inpaint_cl_scratch_bytes_per_frame(h, w) * max_batch + 2048)); hd->inpaint_cl_scratch = p;
+        TRY(dalloc(hd, (uint8_t **)&p, inpaint_win_scratch_bytes(max_batch))); hd->inpaint_win_scratch = p;
         TRY(dalloc(hd, (uint8_t **)&p, unwrap_scratch_bytes_per_frame(h, w) * max_batch + 1024)); hd->unwrap_scratch = p;
         TRY(dalloc(hd, (uint8_t **)&p, (size_t)16 * P * max_batch + 256)); hd->fit_scratch = p;
     }
@@ -632,7 +637,7 @@ int vistaf_ftp_predict_batch(vistaf_ftp_handle *hd, const void *d_frames, int fo
         hipEventSynchronize(hd->ev[ST_COUNT]);
         for (int i = 0; i < ST_COUNT; i++) hipEventElapsedTime(&hd->stage_ms[i], hd->ev[i], hd->ev[i + 1]);
     }
-    if (getenv("VISTAF_TELEA_DBG")) { hipStreamSynchronize(st); telea_debug_dump(); }
+    if (getenv("VISTAF_TELEA_DBG")) { hipStreamSynchronize(st); telea_debug_dump(); telea_window_debug_dump(B); }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VISTAF_E_HIP, std::string("launch: ") + hipGetErrorString(e));
     return 0;

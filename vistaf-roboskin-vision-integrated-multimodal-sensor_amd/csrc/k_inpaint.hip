@@ -135,12 +135,13 @@ __device__ inline float fmm_dist(const uint8_t *f, const float *t, int p, int ec
 // Parallel preparation (one thread per padded cell): Telea flags f (INSIDE on the hole), outside-pass flags fo
 // (ring = within Chebyshev `range` of the hole, seeds = 4-neighbour band), T = 1e6 / 0 on the band, hole count.
 __global__ void k_telea_prep(const uint8_t *__restrict__ bad_all, uint8_t *__restrict__ gflags, float *__restrict__ gT,
-                             int32_t *__restrict__ nbad_all, int range, int h, int w)
+                             int32_t *__restrict__ nbad_all, const int32_t *__restrict__ only, int range, int h, int w)
 {
     const int er = h + 2, ec = w + 2, en = er * ec;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     size_t b = blockIdx.y;
     if (i >= en) return;
+    if (only && !only[b]) return;      // frame already inpainted by the window kernel: its hole count stays 0
     const uint8_t *bad = bad_all + b * (size_t)h * w;
     int y = i / ec, x = i - y * ec;
     auto hole = [&](int yy, int xx) -> bool { return yy >= 1 && yy <= h && xx >= 1 && xx <= w && bad[(size_t)(yy - 1) * w + (xx - 1)] != 0; };
@@ -394,8 +395,8 @@ static size_t telea_lds_bytes(int h, int w)
     return (size_t)TQ_CAP * 8 + 2 * ((en + 15) & ~(size_t)15);
 }
 
-void launch_inpaint_telea(float *img, const uint8_t *bad, int range, void *scratch, int32_t *status, int B, int h, int w,
-                          hipStream_t st)
+void launch_inpaint_telea(float *img, const uint8_t *bad, int range, void *scratch, int32_t *status, const int32_t *only, int B, int h,
+                          int w, hipStream_t st)
 {
     size_t en = (size_t)(h + 2) * (w + 2);
     // scratch layout: [B*en floats T][B*2*en bytes flags]
@@ -404,7 +405,7 @@ void launch_inpaint_telea(float *img, const uint8_t *bad, int range, void *scrat
     uint32_t *gqueue = (uint32_t *)((((uintptr_t)scratch + (size_t)B * en * sizeof(float) + (size_t)B * en * 2) + 255) & ~(uintptr_t)255);
     int32_t *nbad = (int32_t *)(gqueue + (size_t)B * en * 2);
     hipMemsetAsync(nbad, 0, sizeof(int32_t) * B, st);
-    hipLaunchKernelGGL(k_telea_prep, dim3((unsigned)((en + 255) / 256), B), dim3(256), 0, st, bad, gflags, gT, nbad, range, h, w);
+    hipLaunchKernelGGL(k_telea_prep, dim3((unsigned)((en + 255) / 256), B), dim3(256), 0, st, bad, gflags, gT, nbad, only, range, h, w);
     size_t lds_full = telea_lds_bytes(h, w);
     if (lds_full <= 160 * 1024) {
         static bool attr_set = false;

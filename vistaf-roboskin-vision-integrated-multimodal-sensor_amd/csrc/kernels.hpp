@@ -54,8 +54,13 @@ void launch_erode_by_dist(const float *dist, const uint8_t *src, float margin, u
 
 // ---- k_inpaint.hip ----------------------------------------------------------------------------
 size_t inpaint_scratch_bytes_per_frame(int h, int w);
-void launch_inpaint_telea(float *img, const uint8_t *bad, int range, void *scratch, int32_t *status, int B, int h, int w,
+// `only` (device, [B], may be null): process just the frames with only[b] != 0
+void launch_inpaint_telea(float *img, const uint8_t *bad, int range, void *scratch, int32_t *status, const int32_t *only, int B, int h, int w,
                           hipStream_t st);
+
+// ---- k_inpaint_win.hip (LDS-resident window kernel; returns the per-frame fallback flags for launch_inpaint_telea)
+size_t inpaint_win_scratch_bytes(int B);
+int32_t *launch_inpaint_window(float *img, const uint8_t *bad, int range, void *scratch, int B, int h, int w, hipStream_t st);
 
 // ---- k_inpaint_cl.hip (cluster-parallel front end; leaves oversized clusters in *bad_big_out) ----------
 size_t inpaint_cl_scratch_bytes_per_frame(int h, int w);
