@@ -153,9 +153,9 @@ def main():
         P = n * n
         dom = max(acc, key=acc.get)
         # algorithmic bytes of the dominant kernel per launch (DESIGN.md "Kernels"):
-        #   k_unwrap_flood_hot: consumes quality f32 + mask u8 (as rank codes), writes parent i32 -> 9 B/px
+        #   k_unwrap_flood_batch: consumes quality f32 + mask u8 (as rank codes), writes parent i32 -> 9 B/px
         #   k_telea:        reads image f32 + bad-mask u8, writes image f32 -> 9 B/px
-        per_px = {"unwrap flood (k_unwrap_flood_hot)": 9.0, "inpaint (k_telea)": 9.0}.get(dom, 8.0)
+        per_px = {"unwrap flood (k_unwrap_flood_batch)": 9.0, "inpaint (k_telea)": 9.0}.get(dom, 8.0)
         alg_bytes = per_px * P * B
         achieved = alg_bytes / (acc[dom] * 1e-3) / 1e9
         traffic = None

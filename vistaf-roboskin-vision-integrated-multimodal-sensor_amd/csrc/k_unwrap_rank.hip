@@ -19,6 +19,9 @@
 namespace vf {
 
 bool unwrap_hot_supported(int h, int w);
+bool unwrap_batch_supported(int h, int w);
+void launch_unwrap_flood_batch(const uint16_t *rank16, const int32_t *seed, const uint32_t *inv, int32_t *ppar, size_t gstride, int B, int h, int w,
+                               hipStream_t st);
 void launch_unwrap_flood_hot(const uint16_t *rank16, const int32_t *seed, const uint32_t *inv, int32_t *ppar, size_t gstride,
                              int32_t *status, int B, int h, int w, hipStream_t st);
 
@@ -289,9 +292,14 @@ void launch_unwrap_ranked(const float *quality, const uint8_t *mask, uint32_t *g
     int cap = ranked_cap(EN);
     hipLaunchKernelGGL(k_unwrap_rank, dim3(B), dim3(RK_T), 0, st, quality, mask, g0, g1, g2, g3, gstride, rank16, seed, h, w);
     if (ev_flood) hipEventRecord(ev_flood, st);
-    // growth loop: "hot" (sorted register list + rank bitmap, default) or "scan" (frontier array scan)
+    // growth loop: "batch" (default: 8 pops per step, k_unwrap_batch.hip), "hot" (one pop per step, sorted register list + rank
+    // bitmap) or "scan" (frontier array scan)
     static int use_hot = -1;
-    if (use_hot < 0) { const char *e = getenv("VISTAF_FLOOD"); use_hot = (e && !strcmp(e, "scan")) ? 0 : 1; }
+    if (use_hot < 0) { const char *e = getenv("VISTAF_FLOOD"); use_hot = (e && !strcmp(e, "scan")) ? 0 : (e && !strcmp(e, "hot")) ? 1 : 2; }
+    if (use_hot == 2 && unwrap_batch_supported(h, w)) {
+        launch_unwrap_flood_batch(rank16, seed, g1, ppar, gstride, B, h, w, st);
+        return;
+    }
     if (use_hot && unwrap_hot_supported(h, w)) {
         // after the 8 sort passes the sorted (key, index) arrays are back in g0 / g1: g1[rank] = padded pixel index
         launch_unwrap_flood_hot(rank16, seed, g1, ppar, gstride, status, B, h, w, st);
