@@ -67,7 +67,7 @@ struct vistaf_ftp_handle {
     int32_t *labels, *area, *rowdist, *parent;
     unsigned int *peak_bits;
     uint16_t *morph_pre;
-    void *inpaint_scratch, *inpaint_cl_scratch, *inpaint_win_scratch, *unwrap_scratch, *fit_scratch;
+    void *inpaint_scratch, *inpaint_cl_scratch, *inpaint_win_scratch, *unwrap_scratch;
     // small per-frame arrays
     float *thr_hi, *thr_g, *mu, *amp_thr, *thr3, *thr_used, *bg_med, *core_thr, *core_med, *coef;
     int *cnt_a, *cnt_valid, *rel_count, *contact_count, *bg_count, *bad_count, *flipped;
@@ -360,7 +360,6 @@ int vistaf_ftp_create(const vistaf_ftp_config *cfg, int h, int w, int cx, int cy
         TRY(dalloc(hd, (uint8_t **)&p, inpaint_cl_scratch_bytes_per_frame(h, w) * max_batch + 2048)); hd->inpaint_cl_scratch = p;
         TRY(dalloc(hd, (uint8_t **)&p, inpaint_win_scratch_bytes(max_batch))); hd->inpaint_win_scratch = p;
         TRY(dalloc(hd, (uint8_t **)&p, unwrap_scratch_bytes_per_frame(h, w) * max_batch + 1024)); hd->unwrap_scratch = p;
-        TRY(dalloc(hd, (uint8_t **)&p, (size_t)16 * P * max_batch + 256)); hd->fit_scratch = p;
     }
     int pmax = 2 * bwp + 1;
     TRY(dalloc(hd, &hd->patch, (size_t)max_batch * pmax * pmax, "patch", (size_t)pmax * pmax * sizeof(float2)));
@@ -572,8 +571,8 @@ int vistaf_ftp_predict_batch(vistaf_ftp_handle *hd, const void *d_frames, int fo
 
     // ---- plane removal + two-pass detrend (shape_ftp.py:1706, :1716-1751)
     if (timed) hipEventRecord(hd->ev[ST_DETREND], st);
-    launch_robust_polyfit(hd->unwrapped, hd->reliable, c.plane_order_for_removal, c.irls_iters, (float)c.irls_c, 500, hd->coef, hd->phase1, hd->fit_scratch, B, h, w, st);
-    launch_robust_polyfit(hd->phase1, hd->reliable, c.poly_order, c.irls_iters, (float)c.irls_c, 200, hd->coef, hd->resid0, hd->fit_scratch, B, h, w, st);
+    launch_robust_polyfit(hd->unwrapped, hd->reliable, c.plane_order_for_removal, c.irls_iters, (float)c.irls_c, 500, hd->coef, hd->phase1, B, h, w, st);
+    launch_robust_polyfit(hd->phase1, hd->reliable, c.poly_order, c.irls_iters, (float)c.irls_c, 200, hd->coef, hd->resid0, B, h, w, st);
     launch_select(hd->resid0, hd->reliable, (size_t)P, nullptr, true, hd->req_contact, 3, hd->thr3, nullptr, B, P, st);
     launch_contact_mask(hd->resid0, hd->reliable, hd->thr3, hd->rel_count, hd->contact_count, (float)c.min_contact_frac, (float)c.max_contact_frac,
                         hd->contact, hd->thr_used, B, P, st);
@@ -589,7 +588,7 @@ int vistaf_ftp_predict_batch(vistaf_ftp_handle *hd, const void *d_frames, int fo
         if (src != hd->contact_d) HIPCHK(hipMemcpyAsync(hd->contact_d, src, (size_t)B * P, hipMemcpyDeviceToDevice, st));
     }
     launch_background(hd->reliable, hd->contact_d, hd->rel_count, hd->bg_count, hd->background, B, P, st);
-    launch_robust_polyfit(hd->phase1, hd->background, c.poly_order, c.irls_iters, (float)c.irls_c, 200, hd->coef, hd->detr, hd->fit_scratch, B, h, w, st);
+    launch_robust_polyfit(hd->phase1, hd->background, c.poly_order, c.irls_iters, (float)c.irls_c, 200, hd->coef, hd->detr, B, h, w, st);
     launch_select(hd->detr, hd->background, (size_t)P, nullptr, false, hd->req_med, 1, hd->bg_med, nullptr, B, P, st);
 
     // ---- reliable-only smoothing + sign flip (shape_ftp.py:1753-1768)

@@ -37,31 +37,60 @@ __device__ inline float key2f(uint32_t k)
 
 __device__ inline bool finitef(float v) { return (__float_as_uint(v) & 0x7f800000u) != 0x7f800000u; }
 
-// ---- wave-level reductions (xor butterflies through ds_bpermute/DPP as the compiler chooses) ----
-template <typename T>
-__device__ inline T wave_sum(T v)
+// ---- wave-level reductions on the DPP network (no LDS round trips): quad xor 1, quad xor 2, row_half_mirror,
+// row_mirror leave the row result in every lane of a 16-lane row; row_bcast15 / row_bcast31 then carry it
+// across rows so that lane 63 holds the wave result, which is broadcast back through an SGPR.
+template <int CTRL, int RM>
+__device__ inline uint32_t dppmov(uint32_t old, uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, RM, 0xf, false); }
+template <int CTRL, int RM>
+__device__ inline unsigned long long dppmov(unsigned long long old, unsigned long long v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
+    uint32_t lo = dppmov<CTRL, RM>((uint32_t)old, (uint32_t)v), hi = dppmov<CTRL, RM>((uint32_t)(old >> 32), (uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
 }
-__device__ inline uint32_t wave_max_u32(uint32_t v)
+__device__ inline uint32_t bcast63(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
+__device__ inline unsigned long long bcast63(unsigned long long v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(v, o, WAVE); v = t > v ? t : v; }
-    return v;
+    return ((unsigned long long)bcast63((uint32_t)(v >> 32)) << 32) | bcast63((uint32_t)v);
 }
+// RAW = bits of the value (uint32_t or unsigned long long); op combines two RAW words; id = bits of op's identity
+template <typename RAW, typename F>
+__device__ inline RAW wave_reduce_raw(RAW v, RAW id, F op)
+{
+    v = op(v, dppmov<0xB1, 0xf>(v, v));
+    v = op(v, dppmov<0x4E, 0xf>(v, v));
+    v = op(v, dppmov<0x141, 0xf>(v, v));
+    v = op(v, dppmov<0x140, 0xf>(v, v));
+    v = op(v, dppmov<0x142, 0xa>(id, v));
+    v = op(v, dppmov<0x143, 0xc>(id, v));
+    return bcast63(v);
+}
+__device__ inline uint32_t wave_sum(uint32_t v) { return wave_reduce_raw<uint32_t>(v, 0u, [](uint32_t a, uint32_t b) { return a + b; }); }
+__device__ inline int wave_sum(int v) { return (int)wave_sum((uint32_t)v); }
+__device__ inline unsigned long long wave_sum(unsigned long long v)
+{
+    return wave_reduce_raw<unsigned long long>(v, 0ull, [](unsigned long long a, unsigned long long b) { return a + b; });
+}
+__device__ inline float wave_sum(float v)
+{
+    return __uint_as_float(wave_reduce_raw<uint32_t>(__float_as_uint(v), 0u,
+                                                     [](uint32_t a, uint32_t b) { return __float_as_uint(__uint_as_float(a) + __uint_as_float(b)); }));
+}
+__device__ inline double wave_sum(double v)
+{
+    return __longlong_as_double((long long)wave_reduce_raw<unsigned long long>(
+        (unsigned long long)__double_as_longlong(v), 0ull, [](unsigned long long a, unsigned long long b) {
+            return (unsigned long long)__double_as_longlong(__longlong_as_double((long long)a) + __longlong_as_double((long long)b));
+        }));
+}
+__device__ inline uint32_t wave_max_u32(uint32_t v) { return wave_reduce_raw<uint32_t>(v, 0u, [](uint32_t a, uint32_t b) { return b > a ? b : a; }); }
 __device__ inline unsigned long long wave_max_u64(unsigned long long v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_xor(v, o, WAVE); v = t > v ? t : v; }
-    return v;
+    return wave_reduce_raw<unsigned long long>(v, 0ull, [](unsigned long long a, unsigned long long b) { return b > a ? b : a; });
 }
 __device__ inline unsigned long long wave_min_u64(unsigned long long v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_xor(v, o, WAVE); v = t < v ? t : v; }
-    return v;
+    return wave_reduce_raw<unsigned long long>(v, ~0ull, [](unsigned long long a, unsigned long long b) { return b < a ? b : a; });
 }
 
 // block-wide sum for blockDim.x <= 1024; `scratch` must hold 16 elements of T; result valid in all threads

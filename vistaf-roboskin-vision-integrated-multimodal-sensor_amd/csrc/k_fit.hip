@@ -7,125 +7,153 @@
 // in float64 by a block reduction and solved by Cholesky (condition number of the scaled design is
 // O(10), so this is the more accurate of the two).  Medians are exact order statistics (select.hpp).
 // Output plane = z - fit (float32, fit evaluated with the reference's operation order), NaN where z is NaN.
+//
+// Every pass walks the plane itself (z f32 + mask u8 = 5 B/px, coordinates from two LDS tables) with
+// SEL_U / FIT_U independent loads in flight per thread: the passes are bound by memory round trips, not bytes.
 #include "kernels.hpp"
 #include "select.hpp"
 
 namespace vf {
 
-// compacted fit sample: (z, xn, yn) of every pixel with mask != 0 and finite z (deterministic raster order)
+constexpr int FIT_TAB = 4096;     // LDS coordinate tables: xn[w] followed by yn[h] when w + h <= FIT_TAB
+constexpr int FIT_U = 8;          // samples per thread in flight in the normal-equation pass
+
 struct FitCtx {
-    const float4 *comp;
+    const float *z;
+    const uint8_t *m;
+    const float *tab;           // LDS: xn[0..w), yn[0..h)
+    bool use_tab;               // false: divide on the fly (tables too small)
+    int w;
+    uint32_t magic;             // i / w == umulhi(i, magic) (0: plain division; chosen on the host)
+    float cxf, cyf;
     int order;
     float coef[6];
     float med;                  // for the MAD pass
     int mode;                   // 0: key = r, 1: key = |r - med|
-    __device__ inline float resid(const float4 s) const
+    __device__ inline void coords(int i, float &xn, float &yn) const
     {
-        float f = __fmul_rn(coef[0], s.y);
-        f = fmaf(coef[1], s.z, f);
+        int y = magic ? (int)__umulhi((uint32_t)i, magic) : i / w, x = i - y * w;
+        if (use_tab) { xn = tab[x]; yn = tab[w + y]; }
+        else { xn = __fdiv_rn(__fsub_rn((float)x, cxf), cxf); yn = __fdiv_rn(__fsub_rn((float)y, cyf), cyf); }
+    }
+    __device__ inline float resid(float zz, float xn, float yn) const
+    {
+        float f = __fmul_rn(coef[0], xn);
+        f = fmaf(coef[1], yn, f);
         f = __fadd_rn(f, coef[2]);
         if (order >= 2) {
-            f = fmaf(coef[3], __fmul_rn(s.y, s.y), f);
-            f = fmaf(coef[4], __fmul_rn(s.y, s.z), f);
-            f = fmaf(coef[5], __fmul_rn(s.z, s.z), f);
+            f = fmaf(coef[3], __fmul_rn(xn, xn), f);
+            f = fmaf(coef[4], __fmul_rn(xn, yn), f);
+            f = fmaf(coef[5], __fmul_rn(yn, yn), f);
         }
-        return __fsub_rn(s.x, f);
+        return __fsub_rn(zz, f);
     }
-    __device__ bool operator()(int e, uint32_t &key) const
+    __device__ inline bool sample(int i, float &zz, float &xn, float &yn) const
     {
-        float r = resid(comp[e]);
+        zz = z[i];
+        const uint8_t mk = m[i];
+        coords(i, xn, yn);
+        return mk && finitef(zz);
+    }
+    __device__ bool operator()(int i, uint32_t &key) const
+    {
+        float zz, xn, yn;
+        bool ok = sample(i, zz, xn, yn);
+        float r = resid(zz, xn, yn);
         if (mode) r = fabsf(__fsub_rn(r, med));
         key = f2key(r);
-        return true;
+        return ok;
     }
 };
 
-// solve the symmetric positive definite n x n system (n <= 6) in place; returns false if not SPD
-__device__ inline bool chol_solve(double *A, double *rhs, int n)
+// solve the symmetric positive definite N x N system in place (fully unrolled: everything stays in registers);
+// returns false if not SPD
+template <int N>
+__device__ inline bool chol_solve(double (&A)[6][6], double (&rhs)[6])
 {
-    double L[36];
-    for (int i = 0; i < n; i++)
+    double L[N][N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+#pragma unroll
         for (int j = 0; j <= i; j++) {
-            double s = A[i * 6 + j];
-            for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k];
-            if (i == j) { if (!(s > 0.0)) return false; L[i * 6 + i] = sqrt(s); }
-            else L[i * 6 + j] = s / L[j * 6 + j];
+            double s = A[i][j];
+#pragma unroll
+            for (int k = 0; k < j; k++) s -= L[i][k] * L[j][k];
+            if (i == j) { if (!(s > 0.0)) return false; L[i][i] = sqrt(s); }
+            else L[i][j] = s / L[j][j];
         }
-    for (int i = 0; i < n; i++) { double s = rhs[i]; for (int k = 0; k < i; k++) s -= L[i * 6 + k] * rhs[k]; rhs[i] = s / L[i * 6 + i]; }
-    for (int i = n - 1; i >= 0; i--) { double s = rhs[i]; for (int k = i + 1; k < n; k++) s -= L[k * 6 + i] * rhs[k]; rhs[i] = s / L[i * 6 + i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        double s = rhs[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) s -= L[i][k] * rhs[k];
+        rhs[i] = s / L[i][i];
+    }
+#pragma unroll
+    for (int i = N - 1; i >= 0; i--) {
+        double s = rhs[i];
+#pragma unroll
+        for (int k = i + 1; k < N; k++) s -= L[k][i] * rhs[k];
+        rhs[i] = s / L[i][i];
+    }
     return true;
 }
 
 __global__ __launch_bounds__(SEL_T) void k_robust_polyfit(const float *__restrict__ z_all, const uint8_t *__restrict__ mask_all, int order,
                                                           int iters, float c, int min_count, float *__restrict__ coef_out,
-                                                          float *__restrict__ resid_all, float4 *__restrict__ comp_all, int h, int w)
+                                                          float *__restrict__ resid_all, int h, int w, uint32_t magic)
 {
     __shared__ SelShared sh;
-    __shared__ double s_red[16];
+    __shared__ double s_part[16][27];
     __shared__ double s_sum[27];
     __shared__ float s_coef[6];
-    __shared__ uint32_t s_wcnt[16];
+    __shared__ float s_tab[FIT_TAB];
     const size_t b = blockIdx.x;
     const int P = h * w, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int nc = order >= 2 ? 6 : 3;
     const float *z = z_all + b * (size_t)P;
     const uint8_t *m = mask_all + b * (size_t)P;
-    float4 *comp = comp_all + b * (size_t)P;
     const float cxf = (float)((w - 1) / 2.0), cyf = (float)((h - 1) / 2.0);
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-
-    // ---- compaction (wave `wid` owns the contiguous pixel range [p0, p1)): (z, xn, yn) of the fitted pixels
-    const int Lw = (((P + 15) / 16) + 63) & ~63;
-    const int p0 = min(P, wid * Lw), p1 = min(P, p0 + Lw);
-    uint32_t cw = 0;
-    for (int pb = p0; pb < p1; pb += 64) {
-        int p = pb + lane;
-        bool ok = p < p1 && m[p] && finitef(z[p]);
-        cw += (uint32_t)__popcll(__ballot(ok));
+    const bool use_tab = w + h <= FIT_TAB;
+    if (use_tab) {
+        for (int i = tid; i < w + h; i += SEL_T)
+            s_tab[i] = i < w ? __fdiv_rn(__fsub_rn((float)i, cxf), cxf) : __fdiv_rn(__fsub_rn((float)(i - w), cyf), cyf);
     }
-    if (lane == 0) s_wcnt[wid] = cw;
-    __syncthreads();
-    uint32_t off = 0, n = 0;
-    for (int i = 0; i < 16; i++) { uint32_t x = s_wcnt[i]; if (i < wid) off += x; n += x; }
-    const bool do_fit = (int)n >= min_count;
-    if (do_fit) {
-        for (int pb = p0; pb < p1; pb += 64) {
-            int p = pb + lane;
-            float zz = p < p1 ? z[p] : 0.f;
-            bool ok = p < p1 && m[p] && finitef(zz);
-            unsigned long long bm = __ballot(ok);
-            if (ok) {
-                int y = p / w, x = p - y * w;
-                float xn = __fdiv_rn(__fsub_rn((float)x, cxf), cxf), yn = __fdiv_rn(__fsub_rn((float)y, cyf), cyf);
-                comp[off + (uint32_t)__popcll(bm & lt_mask)] = make_float4(zz, xn, yn, 0.f);
-            }
-            off += (uint32_t)__popcll(bm);
-        }
-    }
-    __threadfence();
     __syncthreads();
 
     FitCtx ctx;
-    ctx.comp = comp; ctx.order = order; ctx.med = 0.f; ctx.mode = 0;
+    ctx.z = z; ctx.m = m; ctx.tab = s_tab; ctx.use_tab = use_tab; ctx.w = w; ctx.magic = magic; ctx.cxf = cxf; ctx.cyf = cyf;
+    ctx.order = order; ctx.med = 0.f; ctx.mode = 0;
     for (int i = 0; i < 6; i++) ctx.coef[i] = 0.f;
+
+    // ---- number of fitted pixels (mask != 0 and finite z)
+    uint32_t n;
+    {
+        uint32_t cnt = 0;
+        sel_foreach(ctx, P, [&](uint32_t) { cnt++; });
+        __syncthreads();
+        n = block_sum<uint32_t>(cnt, sh.wsum);
+        __syncthreads();
+    }
+    const bool do_fit = (int)n >= min_count;
+
     float csig = 1.f;      // c * sigma of the previous iteration
     for (int it = 0; do_fit && it < iters; it++) {
-        // ---- weighted normal equations over the compacted samples
+        // ---- weighted normal equations
         double acc[27];
 #pragma unroll
         for (int i = 0; i < 27; i++) acc[i] = 0.0;
-#pragma unroll 2
-        for (int e = tid; e < (int)n; e += SEL_T) {
-            const float4 s = comp[e];
+        auto accumulate = [&](float zz, float xn, float yn) {
             float wt = 1.f;
             if (it > 0) {
-                float u = __fdiv_rn(ctx.resid(s), csig);
+                float u = __fdiv_rn(ctx.resid(zz, xn, yn), csig);
                 wt = __fdiv_rn(1.0f, __fadd_rn(1.0f, __fmul_rn(u, u)));
             }
             float a[6];
-            a[0] = __fmul_rn(s.y, wt); a[1] = __fmul_rn(s.z, wt); a[2] = wt;
-            a[3] = __fmul_rn(__fmul_rn(s.y, s.y), wt); a[4] = __fmul_rn(__fmul_rn(s.y, s.z), wt); a[5] = __fmul_rn(__fmul_rn(s.z, s.z), wt);
-            double zw = (double)__fmul_rn(s.x, wt);
+            a[0] = __fmul_rn(xn, wt); a[1] = __fmul_rn(yn, wt); a[2] = wt;
+            a[3] = __fmul_rn(__fmul_rn(xn, xn), wt); a[4] = __fmul_rn(__fmul_rn(xn, yn), wt); a[5] = __fmul_rn(__fmul_rn(yn, yn), wt);
+            double zw = (double)__fmul_rn(zz, wt);
             int k = 0;
 #pragma unroll
             for (int i = 0; i < 6; i++) {
@@ -134,19 +162,48 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit(const float *__restric
             }
 #pragma unroll
             for (int i = 0; i < 6; i++) acc[21 + i] = fma((double)a[i], zw, acc[21 + i]);
+        };
+        {
+            int i = tid;
+            for (; i + (FIT_U - 1) * SEL_T < P; i += FIT_U * SEL_T) {
+                float zz[FIT_U], xn[FIT_U], yn[FIT_U];
+                bool ok[FIT_U];
+#pragma unroll
+                for (int u = 0; u < FIT_U; u++) ok[u] = ctx.sample(i + u * SEL_T, zz[u], xn[u], yn[u]);
+#pragma unroll
+                for (int u = 0; u < FIT_U; u++)
+                    if (ok[u]) accumulate(zz[u], xn[u], yn[u]);
+            }
+            for (; i < P; i += SEL_T) {
+                float zz, xn, yn;
+                if (ctx.sample(i, zz, xn, yn)) accumulate(zz, xn, yn);
+            }
         }
+        // 27 sums: DPP network inside each wave, then the 16 wave partials in a fixed order
+#pragma unroll
         for (int i = 0; i < 27; i++) {
-            double v = block_sum<double>(acc[i], s_red);
-            if (tid == 0) s_sum[i] = v;
+            double v = wave_sum(acc[i]);
+            if (lane == 0) s_part[wid][i] = v;
+        }
+        __syncthreads();
+        if (tid < 27) {
+            double v = 0.0;
+            for (int k = 0; k < 16; k++) v += s_part[k][tid];
+            s_sum[tid] = v;
         }
         __syncthreads();
         if (tid == 0) {
-            double A[36], rhs[6];
+            double A[6][6], rhs[6];
             int k = 0;
-            for (int i = 0; i < 6; i++)
-                for (int j = i; j < 6; j++) { A[i * 6 + j] = s_sum[k]; A[j * 6 + i] = s_sum[k]; k++; }
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+#pragma unroll
+                for (int j = i; j < 6; j++) { A[i][j] = s_sum[k]; A[j][i] = s_sum[k]; k++; }
+            }
+#pragma unroll
             for (int i = 0; i < 6; i++) rhs[i] = s_sum[21 + i];
-            bool ok = chol_solve(A, rhs, nc);
+            bool ok = nc == 6 ? chol_solve<6>(A, rhs) : chol_solve<3>(A, rhs);
+#pragma unroll
             for (int i = 0; i < 6; i++) s_coef[i] = (ok && i < nc) ? (float)rhs[i] : 0.f;
         }
         __syncthreads();
@@ -155,12 +212,16 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit(const float *__restric
         // ---- sigma = 1.4826 * (median |r - median r| + 1e-6)
         uint32_t nn, kmin, kmax;
         ctx.mode = 0;
-        block_minmax(ctx, (int)n, sh, nn, kmin, kmax);
-        float medr = block_median(ctx, (int)n, sh, nn, kmin, kmax);
+        block_minmax(ctx, P, sh, nn, kmin, kmax);
+        float medr = block_median(ctx, P, sh, nn, kmin, kmax);
         __syncthreads();
         ctx.med = medr; ctx.mode = 1;
-        block_minmax(ctx, (int)n, sh, nn, kmin, kmax);
-        float mad = block_median(ctx, (int)n, sh, nn, kmin, kmax);
+        {
+            // |r - med| lies in [0, max(rmax - med, med - rmin)] (float subtraction is monotone): no second min/max pass
+            float hi1 = fabsf(__fsub_rn(key2f(kmax), medr)), hi2 = fabsf(__fsub_rn(key2f(kmin), medr));
+            kmin = f2key(0.f); kmax = f2key(hi1 > hi2 ? hi1 : hi2);
+        }
+        float mad = block_median(ctx, P, sh, nn, kmin, kmax);
         __syncthreads();
         ctx.mode = 0;
         mad = __fadd_rn(mad, 1e-6f);
@@ -174,8 +235,8 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit(const float *__restric
         float zz = z[p];
         float fit = 0.f;
         if (do_fit) {
-            int y = p / w, x = p - y * w;
-            float xn = __fdiv_rn(__fsub_rn((float)x, cxf), cxf), yn = __fdiv_rn(__fsub_rn((float)y, cyf), cyf);
+            float xn, yn;
+            ctx.coords(p, xn, yn);
             fit = __fadd_rn(__fadd_rn(__fmul_rn(ctx.coef[0], xn), __fmul_rn(ctx.coef[1], yn)), ctx.coef[2]);
             if (order >= 2) {
                 fit = __fadd_rn(fit, __fmul_rn(__fmul_rn(ctx.coef[3], xn), xn));
@@ -189,10 +250,11 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit(const float *__restric
 
 // min_count: 200 upstream (:1103); 500 for the debug_ramp call (shape_ftp.py:1365)
 void launch_robust_polyfit(const float *z, const uint8_t *mask, int order, int iters, float c, int min_count, float *coef_out,
-                           float *resid_out, void *comp_scratch, int B, int h, int w, hipStream_t st)
+                           float *resid_out, int B, int h, int w, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_robust_polyfit, dim3(B), dim3(SEL_T), 0, st, z, mask, order, iters, c, min_count, coef_out, resid_out,
-                       (float4 *)comp_scratch, h, w);
+    // i / w == umulhi(i, magic) for every i < h * w as long as h * w * w < 2^32
+    const uint32_t magic = ((unsigned long long)h * w * w < 0x100000000ull) ? (uint32_t)(0x100000000ull / (unsigned)w) + 1u : 0u;
+    hipLaunchKernelGGL(k_robust_polyfit, dim3(B), dim3(SEL_T), 0, st, z, mask, order, iters, c, min_count, coef_out, resid_out, h, w, magic);
 }
 
 }  // namespace vf

@@ -76,7 +76,7 @@ void launch_unwrap(const float *wrapped, const float *quality, const uint8_t *ma
 
 // ---- k_fit.hip --------------------------------------------------------------------------------
 void launch_robust_polyfit(const float *z, const uint8_t *mask, int order, int iters, float c, int min_count, float *coef_out,
-                           float *resid_out, void *comp_scratch /* 16 bytes per pixel */, int B, int h, int w, hipStream_t st);
+                           float *resid_out, int B, int h, int w, hipStream_t st);
 
 // ---- k_post.hip -------------------------------------------------------------------------------
 struct PostParams {

@@ -23,6 +23,40 @@ struct SelShared {
     uint32_t s_bucket, s_before, s_cnt, s_ncand, s_a, s_b, s_found;
 };
 
+// Visit every valid element (get(i, key) -> bool valid), SEL_U elements per thread at a time: the SEL_U loads of a
+// batch are issued together, so a pass costs P / (SEL_T * SEL_U) memory round trips per thread instead of P / SEL_T.
+constexpr int SEL_U = 8;
+template <class F, class B>
+__device__ inline void sel_foreach(F get, int P, B body)
+{
+    int i = threadIdx.x;
+    for (; i + (SEL_U - 1) * SEL_T < P; i += SEL_U * SEL_T) {
+        uint32_t key[SEL_U];
+        bool ok[SEL_U];
+#pragma unroll
+        for (int u = 0; u < SEL_U; u++) ok[u] = get(i + u * SEL_T, key[u]);
+#pragma unroll
+        for (int u = 0; u < SEL_U; u++)
+            if (ok[u]) body(key[u]);
+    }
+    for (; i < P; i += SEL_T) {
+        uint32_t key;
+        if (get(i, key)) body(key);
+    }
+}
+
+// inclusive prefix sum over the 64 lanes of a wave (DPP row shifts + row broadcasts)
+__device__ inline uint32_t wave_scan_add(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
 // Finds keys of rank k and k+1 (ascending, 0-based) among the n valid elements.
 // get(i, key) -> bool valid.  n must be > 0 and k < n.  Result in all threads.
 template <class F>
@@ -39,20 +73,15 @@ __device__ inline void block_select2(F get, int P, uint32_t n, uint32_t k, SelSh
         int shift = bits > 11 ? bits - 11 : 0;
         for (int i = tid; i < SEL_NB; i += SEL_T) sh.hist[i] = 0;
         __syncthreads();
-        for (int i = tid; i < P; i += SEL_T) {
-            uint32_t key;
-            if (get(i, key) && key >= lo && key <= hi) atomicAdd(&sh.hist[(key - lo) >> shift], 1u);
-        }
+        sel_foreach(get, P, [&](uint32_t key) { if (key >= lo && key <= hi) atomicAdd(&sh.hist[(key - lo) >> shift], 1u); });
         __syncthreads();
         // locate the bucket holding rank (k - below): each thread owns 2 buckets
         uint32_t want = k - below;
         uint32_t c0 = sh.hist[2 * tid], c1 = sh.hist[2 * tid + 1];
         uint32_t mine = c0 + c1;
         // exclusive prefix over threads: wave scan + wave totals
-        uint32_t incl = mine;
         int lane = tid & 63, wid = tid >> 6;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        uint32_t incl = wave_scan_add(mine);
         if (lane == 63) sh.wsum[wid] = incl;
         __syncthreads();
         uint32_t wbase = 0;
@@ -75,10 +104,9 @@ __device__ inline void block_select2(F get, int P, uint32_t n, uint32_t k, SelSh
             // collect candidates of this bucket, rank by counting
             if (tid == 0) sh.s_ncand = 0;
             __syncthreads();
-            for (int i = tid; i < P; i += SEL_T) {
-                uint32_t key;
-                if (get(i, key) && key >= lo && key <= hi) { uint32_t pos = atomicAdd(&sh.s_ncand, 1u); if (pos < SEL_CAND) sh.cand[pos] = key; }
-            }
+            sel_foreach(get, P, [&](uint32_t key) {
+                if (key >= lo && key <= hi) { uint32_t pos = atomicAdd(&sh.s_ncand, 1u); if (pos < SEL_CAND) sh.cand[pos] = key; }
+            });
             __syncthreads();
             uint32_t m = sh.s_ncand;
             uint32_t want2 = k - below;
@@ -100,10 +128,7 @@ __device__ inline void block_select2(F get, int P, uint32_t n, uint32_t k, SelSh
     {
         uint32_t le = 0;
         unsigned long long nxt = ~0ull;
-        for (int i = tid; i < P; i += SEL_T) {
-            uint32_t key;
-            if (get(i, key)) { le += key <= a; if (key > a && (unsigned long long)key < nxt) nxt = key; }
-        }
+        sel_foreach(get, P, [&](uint32_t key) { le += key <= a; if (key > a && (unsigned long long)key < nxt) nxt = key; });
         __syncthreads();
         uint32_t tot = block_sum<uint32_t>(le, sh.wsum);
         unsigned long long mn = block_min_u64(nxt, sh.red64);
@@ -119,10 +144,7 @@ __device__ inline void block_minmax(F get, int P, SelShared &sh, uint32_t &n, ui
 {
     uint32_t c = 0;
     unsigned long long mn = ~0ull, mx = 0;
-    for (int i = threadIdx.x; i < P; i += SEL_T) {
-        uint32_t key;
-        if (get(i, key)) { c++; if (key < mn) mn = key; if (key + 1ull > mx) mx = key + 1ull; }
-    }
+    sel_foreach(get, P, [&](uint32_t key) { c++; if (key < mn) mn = key; if (key + 1ull > mx) mx = key + 1ull; });
     __syncthreads();
     n = block_sum<uint32_t>(c, sh.wsum);
     mn = block_min_u64(mn, sh.red64);
