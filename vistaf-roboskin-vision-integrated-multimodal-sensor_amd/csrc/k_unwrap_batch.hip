@@ -36,7 +36,7 @@ __device__ inline int bt_scan_add(int v)
 }
 
 __global__ __launch_bounds__(64) void k_unwrap_flood_batch(const uint16_t *__restrict__ rank_all, const int32_t *__restrict__ seed_in,
-                                                           const uint32_t *__restrict__ inv_all, int32_t *__restrict__ ppar_all,
+                                                           const uint32_t *__restrict__ inv_all, size_t inv_stride, int32_t *__restrict__ ppar_all,
                                                            size_t gstride, int h, int w, uint32_t magic)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_batch(const uint16_t *__res
     uint32_t *stage = (uint32_t *)(L1 + 16);                             // [64]    refill staging
     int32_t *ppar = ppar_all + b * gstride;
     const uint16_t *rk = rank_all + b * (size_t)EN8;
-    const uint32_t *inv = inv_all + b * gstride;                         // inv[rank] = padded pixel index
+    const uint32_t *inv = inv_all + b * inv_stride;                         // inv[rank] = padded pixel index
 
     {
         const uint4 *src = (const uint4 *)rk;
@@ -215,7 +215,7 @@ bool unwrap_batch_supported(int h, int w)
     return EN <= 65533 && lds <= 160 * 1024;
 }
 
-void launch_unwrap_flood_batch(const uint16_t *rank16, const int32_t *seed, const uint32_t *inv, int32_t *ppar, size_t gstride,
+void launch_unwrap_flood_batch(const uint16_t *rank16, const int32_t *seed, const uint32_t *inv, size_t inv_stride, int32_t *ppar, size_t gstride,
                                int B, int h, int w, hipStream_t st)
 {
     long EN = (long)(h + 2) * (w + 2);
@@ -223,7 +223,7 @@ void launch_unwrap_flood_batch(const uint16_t *rank16, const int32_t *seed, cons
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_unwrap_flood_batch, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
     const uint32_t magic = (uint32_t)(0x100000000ull / (unsigned)(w + 2)) + 1u;     // idx / (w + 2) == umulhi(idx, magic) for idx < 65536
-    hipLaunchKernelGGL(k_unwrap_flood_batch, dim3(B), dim3(64), lds, st, rank16, seed, inv, ppar, gstride, h, w, magic);
+    hipLaunchKernelGGL(k_unwrap_flood_batch, dim3(B), dim3(64), lds, st, rank16, seed, inv, inv_stride, ppar, gstride, h, w, magic);
 }
 
 }  // namespace vf

@@ -40,7 +40,7 @@ __device__ unsigned long long g_flood_dbg[16];
 constexpr int HOT_NW = 1024;   // 64-bit words of the code bitmap (codes < 65536)
 
 __global__ __launch_bounds__(64) void k_unwrap_flood_hot(const uint16_t *__restrict__ rank_all, const int32_t *__restrict__ seed_in,
-                                                         const uint32_t *__restrict__ inv_all, int32_t *__restrict__ ppar_all,
+                                                         const uint32_t *__restrict__ inv_all, size_t inv_stride, int32_t *__restrict__ ppar_all,
                                                          size_t gstride, int32_t *status, int h, int w)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_hot(const uint16_t *__restr
     uint32_t *stage = (uint32_t *)(L1 + 16);                             // [64]     refill staging
     int32_t *ppar = ppar_all + b * gstride;
     const uint16_t *rk = rank_all + b * (size_t)EN8;
-    const uint32_t *inv = inv_all + b * gstride;                         // inv[rank] = padded pixel index
+    const uint32_t *inv = inv_all + b * inv_stride;                         // inv[rank] = padded pixel index
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     {
@@ -221,14 +221,14 @@ bool unwrap_hot_supported(int h, int w)
     return EN <= 65533 && lds <= 160 * 1024;
 }
 
-void launch_unwrap_flood_hot(const uint16_t *rank16, const int32_t *seed, const uint32_t *inv, int32_t *ppar, size_t gstride,
+void launch_unwrap_flood_hot(const uint16_t *rank16, const int32_t *seed, const uint32_t *inv, size_t inv_stride, int32_t *ppar, size_t gstride,
                              int32_t *status, int B, int h, int w, hipStream_t st)
 {
     long EN = (long)(h + 2) * (w + 2);
     size_t lds = (size_t)(((EN + 7) & ~7L)) * 2 + (HOT_NW + 16) * 8 + 256;
     static bool attr_set = false;
     if (!attr_set) { hipFuncSetAttribute((const void *)k_unwrap_flood_hot, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-    hipLaunchKernelGGL(k_unwrap_flood_hot, dim3(B), dim3(64), lds, st, rank16, seed, inv, ppar, gstride, status, h, w);
+    hipLaunchKernelGGL(k_unwrap_flood_hot, dim3(B), dim3(64), lds, st, rank16, seed, inv, inv_stride, ppar, gstride, status, h, w);
     if (getenv("VISTAF_FLOOD_DBG")) {
         hipStreamSynchronize(st);
         unsigned long long g[16];

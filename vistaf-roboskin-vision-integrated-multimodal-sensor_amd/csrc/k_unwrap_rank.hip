@@ -4,7 +4,7 @@
 // k_unwrap_rank   (1024 threads / frame) replaces each masked pixel's float quality by its RANK in the
 //                 frame's total order (q ascending, ties: larger pixel index first, so that the larger
 //                 rank is exactly the reference heap's higher priority "-q, then smaller (y, x)").
-//                 Stable LSD radix sort, 4-bit digits, thread-contiguous chunks.  The rank codes are
+//                 Stable LSD radix sort, 8-bit digits (4 passes), wave-contiguous chunks, 4 tiles of loads in flight.  The rank codes are
 //                 written into a plane padded by one pixel of zeros on every side.
 // k_unwrap_flood_ranked (one wavefront / frame) holds the whole padded frame in LDS as one uint16 per
 //                 pixel (0 outside mask / border, 1 visited, 2 in frontier, >= 3 untouched with
@@ -15,14 +15,15 @@
 #include <cstdlib>
 #include <cstring>
 #include "kernels.hpp"
+#include "select.hpp"
 
 namespace vf {
 
 bool unwrap_hot_supported(int h, int w);
 bool unwrap_batch_supported(int h, int w);
-void launch_unwrap_flood_batch(const uint16_t *rank16, const int32_t *seed, const uint32_t *inv, int32_t *ppar, size_t gstride, int B, int h, int w,
+void launch_unwrap_flood_batch(const uint16_t *rank16, const int32_t *seed, const uint32_t *inv, size_t inv_stride, int32_t *ppar, size_t gstride, int B, int h, int w,
                                hipStream_t st);
-void launch_unwrap_flood_hot(const uint16_t *rank16, const int32_t *seed, const uint32_t *inv, int32_t *ppar, size_t gstride,
+void launch_unwrap_flood_hot(const uint16_t *rank16, const int32_t *seed, const uint32_t *inv, size_t inv_stride, int32_t *ppar, size_t gstride,
                              int32_t *status, int B, int h, int w, hipStream_t st);
 
 constexpr int RK_T = 1024;
@@ -53,23 +54,28 @@ __device__ inline uint32_t dpp_max8_u32(uint32_t v)
 // rank plane layout: [(h+2) x (w+2)] uint16 (frame stride padded to 8 elements), border = 0.
 // Sort structure: each of the 16 waves owns a contiguous range of the element array and walks it in
 // 64-element tiles (coalesced, L1-bypassing loads of data other waves wrote in the previous pass).
-// Counting uses a per-wave 16-bin LDS histogram; the stable scatter ranks a lane among the lanes of its
-// tile that share its digit with four ballots (peer mask) + mbcnt.
+// Counting uses a per-wave 256-bin LDS histogram; the stable scatter ranks a lane among the lanes of its
+// tile that share its digit with eight ballots (peer mask) + mbcnt.
 __device__ inline uint32_t ld_u32c(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline unsigned long long ld_u64c(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+constexpr int RK_U = 4;        // 64-element tiles in flight per wave (independent loads issued together)
 
 __global__ __launch_bounds__(RK_T) void k_unwrap_rank(const float *__restrict__ quality_all, const uint8_t *__restrict__ mask_all,
-                                                      uint32_t *kA_all, uint32_t *iA_all, uint32_t *kB_all, uint32_t *iB_all,
+                                                      unsigned long long *A_all, unsigned long long *B_all,
                                                       size_t gstride, uint16_t *__restrict__ rank_all, int32_t *__restrict__ seed_out,
                                                       int h, int w)
 {
-    __shared__ uint32_t whist[16][16];     // [wave][digit] counts, then exclusive offsets
+    // sort records: key << 32 | padded pixel index (one 8-byte scattered store per element and pass)
+    __shared__ uint32_t whist[16][256];    // [wave][digit] counts, then exclusive offsets
     __shared__ uint32_t wcount[16];
     const size_t b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int P = h * w, W2 = w + 2, EN = (h + 2) * W2;
     const float *q = quality_all + b * (size_t)P;
     const uint8_t *m = mask_all + b * (size_t)P;
-    uint32_t *kA = kA_all + b * gstride, *iA = iA_all + b * gstride, *kB = kB_all + b * gstride, *iB = iB_all + b * gstride;
+    unsigned long long *rA = A_all + b * gstride, *rB = B_all + b * gstride;
+    uint32_t *inv = (uint32_t *)rB;             // reuses this frame's rB once the last pass has left the records in rA
     uint16_t *rk = rank_all + b * (size_t)((EN + 7) & ~7);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
@@ -78,87 +84,109 @@ __global__ __launch_bounds__(RK_T) void k_unwrap_rank(const float *__restrict__ 
     const int Lw = (((P + 15) / 16) + 63) & ~63;
     const int r0 = min(P, wid * Lw), r1 = min(P, r0 + Lw);
     uint32_t c = 0;
-    for (int rb = r0; rb < r1; rb += 64) {
-        int r = rb + lane;
-        bool in = r < r1 && m[P - 1 - r] != 0;
-        c += (uint32_t)__popcll(__ballot(in));
+    for (int rb = r0; rb < r1; rb += 64 * RK_U) {
+        uint8_t mm[RK_U];
+#pragma unroll
+        for (int u = 0; u < RK_U; u++) { int r = rb + u * 64 + lane; mm[u] = r < r1 ? m[P - 1 - r] : (uint8_t)0; }
+#pragma unroll
+        for (int u = 0; u < RK_U; u++) c += (uint32_t)__popcll(__ballot(mm[u] != 0));
     }
     if (lane == 0) wcount[wid] = c;
     __syncthreads();
     uint32_t off = 0, n = 0;
     for (int i = 0; i < 16; i++) { uint32_t x = wcount[i]; if (i < wid) off += x; n += x; }
-    for (int rb = r0; rb < r1; rb += 64) {
-        int r = rb + lane;
-        bool in = r < r1 && m[P - 1 - r] != 0;
-        unsigned long long bm = __ballot(in);
-        if (in) {
-            int p = P - 1 - r;
-            int y = p / w, x = p - y * w;
-            uint32_t o = off + (uint32_t)__popcll(bm & lt_mask);
-            kA[o] = f2key(q[p]);
-            iA[o] = (uint32_t)((y + 1) * W2 + x + 1);
+    for (int rb = r0; rb < r1; rb += 64 * RK_U) {
+        uint8_t mm[RK_U];
+        float qq[RK_U];
+#pragma unroll
+        for (int u = 0; u < RK_U; u++) {
+            int r = rb + u * 64 + lane;
+            bool in = r < r1;
+            mm[u] = in ? m[P - 1 - r] : (uint8_t)0;
+            qq[u] = in ? q[P - 1 - r] : 0.f;
         }
-        off += (uint32_t)__popcll(bm);
+#pragma unroll
+        for (int u = 0; u < RK_U; u++) {
+            bool in = mm[u] != 0;
+            unsigned long long bm = __ballot(in);
+            if (in) {
+                int p = P - 1 - (rb + u * 64 + lane);
+                int y = p / w, x = p - y * w;
+                uint32_t o = off + (uint32_t)__popcll(bm & lt_mask);
+                rA[o] = ((unsigned long long)f2key(qq[u]) << 32) | (uint32_t)((y + 1) * W2 + x + 1);
+            }
+            off += (uint32_t)__popcll(bm);
+        }
     }
     if (tid == 0 && n == 0) seed_out[b] = -1;
     __threadfence();
     __syncthreads();
     if (n == 0) return;
 
-    // 2. stable LSD radix sort, 8 passes of 4 bits; wave `wid` owns elements [e0, e1)
+    // 2. stable LSD radix sort, 4 passes of 8 bits; wave `wid` owns elements [e0, e1)
     const int Mw = ((((int)n + 15) / 16) + 63) & ~63;
     const int e0 = min((int)n, wid * Mw), e1 = min((int)n, e0 + Mw);
-    uint32_t *ks = kA, *is = iA, *kd = kB, *id = iB;
-    for (int pass = 0; pass < 8; pass++) {
-        const int shift = pass * 4;
-        if (lane < 16) whist[wid][lane] = 0;
-        for (int eb = e0; eb < e1; eb += 64) {
-            int e = eb + lane;
-            if (e < e1) atomicAdd(&whist[wid][(ld_u32c(&ks[e]) >> shift) & 15u], 1u);
-        }
-        __syncthreads();
-        // exclusive offsets in (digit-major, wave-minor) order, computed by the first 256 threads
-        if (tid < 256) {
-            int d = tid >> 4, wv = tid & 15;
-            uint32_t v = whist[wv][d];
-            uint32_t incl = v;
+    unsigned long long *rs = rA, *rd = rB;
+    for (int pass = 0; pass < 4; pass++) {
+        const int shift = pass * 8;
+        for (int i = lane; i < 256; i += 64) whist[wid][i] = 0;
+        for (int eb = e0; eb < e1; eb += 64 * RK_U) {
+            uint32_t kk[RK_U];
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-            if (lane == 63) wcount[tid >> 6] = incl;
-            whist[wv][d] = incl - v;       // wave-local exclusive prefix; wave totals added after the block barrier
+            for (int u = 0; u < RK_U; u++) { int e = eb + u * 64 + lane; kk[u] = e < e1 ? ld_u32c((const uint32_t *)&rs[e] + 1) : 0u; }
+#pragma unroll
+            for (int u = 0; u < RK_U; u++)
+                if (eb + u * 64 + lane < e1) atomicAdd(&whist[wid][(kk[u] >> shift) & 255u], 1u);
         }
         __syncthreads();
-        if (tid < 256) {
+        // exclusive offsets in (digit-major, wave-minor) order: thread t owns digit t >> 2, waves 4 * (t & 3) .. + 3
+        {
+            const int dg = tid >> 2, w0 = (tid & 3) * 4;
+            uint32_t v0 = whist[w0][dg], v1 = whist[w0 + 1][dg], v2 = whist[w0 + 2][dg], v3 = whist[w0 + 3][dg];
+            uint32_t mine = v0 + v1 + v2 + v3;
+            uint32_t incl = wave_scan_add(mine);
+            if (lane == 63) wcount[wid] = incl;
+            __syncthreads();
             uint32_t add = 0;
-            for (int i = 0; i < (tid >> 6); i++) add += wcount[i];
-            whist[tid & 15][tid >> 4] += add;
+            for (int i = 0; i < wid; i++) add += wcount[i];
+            uint32_t ex = add + incl - mine;
+            whist[w0][dg] = ex; whist[w0 + 1][dg] = ex + v0; whist[w0 + 2][dg] = ex + v0 + v1; whist[w0 + 3][dg] = ex + v0 + v1 + v2;
         }
         __syncthreads();
-        for (int eb = e0; eb < e1; eb += 64) {
-            int e = eb + lane;
-            bool ok = e < e1;
-            uint32_t k = ok ? ld_u32c(&ks[e]) : 0u, ix = ok ? ld_u32c(&is[e]) : 0u;
-            uint32_t d = (k >> shift) & 15u;
-            unsigned long long peers = __ballot(ok);
+        for (int eb = e0; eb < e1; eb += 64 * RK_U) {
+            unsigned long long rr[RK_U];
 #pragma unroll
-            for (int bit = 0; bit < 4; bit++) {
-                unsigned long long bm = __ballot(ok && ((d >> bit) & 1u));
-                peers &= ((d >> bit) & 1u) ? bm : ~bm;
+            for (int u = 0; u < RK_U; u++) {
+                int e = eb + u * 64 + lane;
+                rr[u] = e < e1 ? ld_u64c(&rs[e]) : 0ull;
             }
-            uint32_t base = whist[wid][d];
-            uint32_t rnk = (uint32_t)__popcll(peers & lt_mask);
-            if (ok) { kd[base + rnk] = k; id[base + rnk] = ix; }
-            if (ok && rnk == 0) whist[wid][d] = base + (uint32_t)__popcll(peers);
+#pragma unroll
+            for (int u = 0; u < RK_U; u++) {
+                const bool ok = eb + u * 64 + lane < e1;
+                const uint32_t dgt = (uint32_t)(rr[u] >> (32 + shift)) & 255u;
+                unsigned long long peers = __ballot(ok);
+#pragma unroll
+                for (int bit = 0; bit < 8; bit++) {
+                    unsigned long long bm = __ballot(ok && ((dgt >> bit) & 1u));
+                    peers &= ((dgt >> bit) & 1u) ? bm : ~bm;
+                }
+                const uint32_t base = whist[wid][dgt];
+                const uint32_t rnk = (uint32_t)__popcll(peers & lt_mask);
+                if (ok) rd[base + rnk] = rr[u];
+                __builtin_amdgcn_wave_barrier();
+                if (ok && rnk == 0) whist[wid][dgt] = base + (uint32_t)__popcll(peers);
+                __builtin_amdgcn_wave_barrier();
+            }
         }
         __threadfence();
         __syncthreads();
-        uint32_t *t = ks; ks = kd; kd = t;
-        t = is; is = id; id = t;
+        unsigned long long *t = rs; rs = rd; rd = t;
     }
-    // 3. rank = sorted position (ascending priority); uint16 code = rank + 3
+    // 3. rank = sorted position (ascending priority); uint16 code = rank + 3; inv[rank] = padded pixel index
     for (int e = tid; e < (int)n; e += RK_T) {
-        uint32_t ix = ld_u32c(&is[e]);
+        uint32_t ix = (uint32_t)ld_u64c(&rs[e]);
         rk[ix] = (uint16_t)(e + 3);
+        inv[e] = ix;
         if (e == (int)n - 1) seed_out[b] = (int32_t)ix;
     }
 }
@@ -290,19 +318,21 @@ void launch_unwrap_ranked(const float *quality, const uint8_t *mask, uint32_t *g
 {
     int EN = (h + 2) * (w + 2);
     int cap = ranked_cap(EN);
-    hipLaunchKernelGGL(k_unwrap_rank, dim3(B), dim3(RK_T), 0, st, quality, mask, g0, g1, g2, g3, gstride, rank16, seed, h, w);
+    // g0|g1 and g2|g3 are contiguous (k_unwrap.hip): two planes of 8-byte sort records; the sorted pixel indices go to g2
+    (void)g1; (void)g3;
+    hipLaunchKernelGGL(k_unwrap_rank, dim3(B), dim3(RK_T), 0, st, quality, mask, (unsigned long long *)g0, (unsigned long long *)g2, gstride,
+                       rank16, seed, h, w);
     if (ev_flood) hipEventRecord(ev_flood, st);
     // growth loop: "batch" (default: 8 pops per step, k_unwrap_batch.hip), "hot" (one pop per step, sorted register list + rank
     // bitmap) or "scan" (frontier array scan)
     static int use_hot = -1;
     if (use_hot < 0) { const char *e = getenv("VISTAF_FLOOD"); use_hot = (e && !strcmp(e, "scan")) ? 0 : (e && !strcmp(e, "hot")) ? 1 : 2; }
     if (use_hot == 2 && unwrap_batch_supported(h, w)) {
-        launch_unwrap_flood_batch(rank16, seed, g1, ppar, gstride, B, h, w, st);
+        launch_unwrap_flood_batch(rank16, seed, g2, 2 * gstride, ppar, gstride, B, h, w, st);
         return;
     }
     if (use_hot && unwrap_hot_supported(h, w)) {
-        // after the 8 sort passes the sorted (key, index) arrays are back in g0 / g1: g1[rank] = padded pixel index
-        launch_unwrap_flood_hot(rank16, seed, g1, ppar, gstride, status, B, h, w, st);
+        launch_unwrap_flood_hot(rank16, seed, g2, 2 * gstride, ppar, gstride, status, B, h, w, st);
         return;
     }
     static bool attr_set = false;
