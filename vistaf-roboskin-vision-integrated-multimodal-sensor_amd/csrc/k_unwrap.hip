@@ -207,9 +207,11 @@ size_t unwrap_scratch_bytes_per_frame(int h, int w)
 }
 
 bool unwrap_ranked_supported(int h, int w);
-void launch_unwrap_ranked(const float *quality, const uint8_t *mask, uint32_t *g0, uint32_t *g1, uint32_t *g2, uint32_t *g3,
+bool launch_unwrap_ranked(const float *quality, const uint8_t *mask, uint32_t *g0, uint32_t *g1, uint32_t *g2, uint32_t *g3,
                           int32_t *ppar, size_t gstride, uint16_t *rank16, int32_t *seed, int32_t *status, int B, int h, int w,
                           hipStream_t st, hipEvent_t ev_flood);
+void launch_unwrap_replay(const float *wrapped, const uint32_t *order, size_t ostride, int32_t *tree, float *unwrapped, int B, int h, int w,
+                          hipStream_t st);
 
 static int unwrap_lds_cap(int P)
 {
@@ -236,8 +238,13 @@ void launch_unwrap(const float *wrapped, const float *quality, const uint8_t *ma
         after = (uint8_t *)(((uintptr_t)after + 255) & ~(uintptr_t)255);
         uint16_t *rank16 = (uint16_t *)after;
         int32_t *seed = (int32_t *)(after + (((gn + 8 * (size_t)B) * 2 + 255) & ~(size_t)255));
-        launch_unwrap_ranked(quality, mask, g0, g1, g2, g3, (int32_t *)g4, EN, rank16, seed, status, B, h, w, st, ev_flood);
+        bool logged = launch_unwrap_ranked(quality, mask, g0, g1, g2, g3, (int32_t *)g4, EN, rank16, seed, status, B, h, w, st, ev_flood);
         ppar = (const int32_t *)g4;
+        if (logged) {
+            if (ev_mid) hipEventRecord(ev_mid, st);
+            launch_unwrap_replay(wrapped, g0, 2 * EN, parent, unwrapped, B, h, w, st);
+            return;
+        }
     } else if (cap > 0) {
         if (ev_flood) hipEventRecord(ev_flood, st);
         static bool attr_set = false;

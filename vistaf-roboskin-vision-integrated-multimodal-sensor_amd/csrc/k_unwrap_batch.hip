@@ -37,13 +37,15 @@ __device__ inline int bt_scan_add(int v)
 
 __global__ __launch_bounds__(64) void k_unwrap_flood_batch(const uint16_t *__restrict__ rank_all, const int32_t *__restrict__ seed_in,
                                                            const uint32_t *__restrict__ inv_all, size_t inv_stride, int32_t *__restrict__ ppar_all,
-                                                           size_t gstride, int h, int w, uint32_t magic)
+                                                           size_t gstride, uint32_t *__restrict__ order_all, size_t ostride, int h, int w, uint32_t magic)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x;
     const size_t b = blockIdx.x;
     const int W2 = w + 2, EN = (h + 2) * W2;
     const int EN8 = (EN + 7) & ~7;
+    uint32_t *order = order_all + b * ostride;                           // pop record: parent << 16 | pixel (padded indices); order[ostride-1] = count
+    int npop = 0;
     uint16_t *kp = (uint16_t *)lds_raw;                                  // [EN8] pixel state / rank code
     unsigned long long *L0 = (unsigned long long *)(kp + EN8);           // [BT_NW] cold bitmap over codes
     unsigned long long *L1 = L0 + BT_NW;                                 // [16]    one bit per L0 word
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_batch(const uint16_t *__res
     for (int p = lane; p < EN; p += 64) ppar[p] = -1;
     __syncthreads();
     const int seed = __builtin_amdgcn_readfirstlane(seed_in[b]);
-    if (seed < 0) return;                                                // empty mask (shape_ftp.py:1047-1048)
+    if (seed < 0) { if (lane == 0) order[ostride - 1] = 0u; return; }   // empty mask (shape_ftp.py:1047-1048)
     const int ci = lane >> 3, n = lane & 7;                              // candidate slot, neighbour slot
     int doff;
     {
@@ -163,8 +165,13 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_batch(const uint16_t *__res
         const unsigned long long visb = __ballot(act && v == 1u);
         const uint32_t grp = (uint32_t)(visb >> (ci * 8)) & 0xffu;
         // parent = lexicographically smallest visited neighbour = lowest neighbour slot with state 1
-        if (act && v == 1u && (grp & ((1u << n) - 1u)) == 0u) ppar[idx] = np;
-        if (act && n == 0) kp[idx] = 1;
+        const bool isp = act && v == 1u && (grp & ((1u << n) - 1u)) == 0u;
+        if (isp) { ppar[idx] = np; order[npop + ci] = ((uint32_t)np << 16) | (uint32_t)idx; }
+        if (act && n == 0) {
+            kp[idx] = 1;
+            if (grp == 0u) order[npop + ci] = ((uint32_t)idx << 16) | (uint32_t)idx;      // the seed: no visited neighbour, its own parent
+        }
+        npop += m;
         const bool ins = act && fresh;
         if (ins) kp[np] = 2;
         // drop the m popped entries from HOT
@@ -206,6 +213,74 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_batch(const uint16_t *__res
         }
         if (coldb) cold_any = true;
     }
+    if (lane == 0) order[ostride - 1] = (uint32_t)npop;
+}
+
+// k_unwrap_replay: integer wrap counts along the growth tree (shape_ftp.py:1060-1076) by replaying the pops in order.
+// A pixel's count is its parent's plus the wrap of the phase step between them, and a parent always pops before
+// its children, so walking the pop records front to back resolves everything in one sweep.  The counts live in
+// LDS (int16 per padded pixel, RP_UNSET = not yet known); each wave takes every RP_NW-th chunk of 64 records,
+// prefetches its phase values and spins on the parents' LDS entries, which earlier chunks (other waves) fill in.
+constexpr int RP_NW = 8;
+constexpr int16_t RP_UNSET = (int16_t)0x7fff;
+
+__global__ __launch_bounds__(64 * RP_NW) void k_unwrap_replay(const float *__restrict__ wrapped_all, const uint32_t *__restrict__ order_all,
+                                                              size_t ostride, int32_t *__restrict__ tree_all, float *__restrict__ unwrapped_all,
+                                                              int h, int w, uint32_t magic)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    int16_t *ks = (int16_t *)lds_raw;                                     // [EN8]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const size_t b = blockIdx.x;
+    const int P = h * w, W2 = w + 2, EN = (h + 2) * W2;
+    const uint32_t *order = order_all + b * ostride;
+    const float *wrapped = wrapped_all + b * (size_t)P;
+    int32_t *tree = tree_all + b * (size_t)P;
+    float *unwrapped = unwrapped_all + b * (size_t)P;
+    const double twopi = 6.283185307179586476925286766559, pi_d = 3.14159265358979323846;
+    {
+        uint32_t fill = ((uint32_t)(uint16_t)RP_UNSET << 16) | (uint16_t)RP_UNSET;
+        uint32_t *k32 = (uint32_t *)ks;
+        for (int i = tid; i < ((EN + 7) & ~7) / 2; i += 64 * RP_NW) k32[i] = fill;
+    }
+    const int npop = (int)order[ostride - 1];
+    __syncthreads();
+    for (int c0 = wid * 64; c0 < npop; c0 += 64 * RP_NW) {
+        const int i = c0 + lane;
+        const bool valid = i < npop;
+        const uint32_t rec = valid ? order[i] : 0u;
+        const int idx = (int)(rec & 0xffffu), pp = (int)(rec >> 16);
+        const int y = (int)__umulhi((uint32_t)idx, magic), x = idx - y * W2;
+        const int py = (int)__umulhi((uint32_t)pp, magic), px = pp - py * W2;
+        const int p = valid ? (y - 1) * w + (x - 1) : 0, par = valid ? (py - 1) * w + (px - 1) : 0;
+        const float wp = wrapped[p], wq = wrapped[par];
+        int v = 0;
+        if (pp != idx) {
+            double dd0 = (double)wp - (double)wq;
+            double k = -rint(dd0 / twopi);
+            double dd = dd0 + twopi * k;
+            if (dd <= -pi_d) k += 1.0;
+            else if (dd > pi_d) k -= 1.0;
+            v = (int)k;
+        }
+        bool done = !valid;
+        int kf = 0;
+        if (valid && pp == idx) { done = true; __hip_atomic_store(&ks[idx], (int16_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+        while (__ballot(!done)) {
+            if (!done) {
+                int16_t kq = __hip_atomic_load(&ks[pp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (kq != RP_UNSET) {
+                    kf = (int)kq + v;
+                    __hip_atomic_store(&ks[idx], (int16_t)kf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    done = true;
+                }
+            }
+        }
+        if (valid) {
+            unwrapped[p] = (float)((double)wp + twopi * (double)kf);
+            tree[p] = par;
+        }
+    }
 }
 
 bool unwrap_batch_supported(int h, int w)
@@ -216,14 +291,29 @@ bool unwrap_batch_supported(int h, int w)
 }
 
 void launch_unwrap_flood_batch(const uint16_t *rank16, const int32_t *seed, const uint32_t *inv, size_t inv_stride, int32_t *ppar, size_t gstride,
-                               int B, int h, int w, hipStream_t st)
+                               uint32_t *order, size_t ostride, int B, int h, int w, hipStream_t st)
 {
     long EN = (long)(h + 2) * (w + 2);
     size_t lds = (size_t)(((EN + 7) & ~7L)) * 2 + (BT_NW + 16) * 8 + 256;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_unwrap_flood_batch, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
     const uint32_t magic = (uint32_t)(0x100000000ull / (unsigned)(w + 2)) + 1u;     // idx / (w + 2) == umulhi(idx, magic) for idx < 65536
-    hipLaunchKernelGGL(k_unwrap_flood_batch, dim3(B), dim3(64), lds, st, rank16, seed, inv, inv_stride, ppar, gstride, h, w, magic);
+    hipLaunchKernelGGL(k_unwrap_flood_batch, dim3(B), dim3(64), lds, st, rank16, seed, inv, inv_stride, ppar, gstride, order, ostride, h, w, magic);
+}
+
+// unwrapped = wrapped + 2*pi*k along the growth tree; NaN / parent -1 where the growth never arrived
+void launch_unwrap_replay(const float *wrapped, const uint32_t *order, size_t ostride, int32_t *tree, float *unwrapped, int B, int h, int w,
+                          hipStream_t st)
+{
+    const size_t n = (size_t)B * h * w;
+    (void)hipMemsetAsync(tree, 0xff, n * sizeof(int32_t), st);
+    (void)hipMemsetD32Async((hipDeviceptr_t)unwrapped, 0x7fc00000, n, st);
+    long EN = (long)(h + 2) * (w + 2);
+    size_t lds = (size_t)(((EN + 7) & ~7L)) * 2;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_unwrap_replay, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    const uint32_t magic = (uint32_t)(0x100000000ull / (unsigned)(w + 2)) + 1u;
+    hipLaunchKernelGGL(k_unwrap_replay, dim3(B), dim3(64 * RP_NW), lds, st, wrapped, order, ostride, tree, unwrapped, h, w, magic);
 }
 
 }  // namespace vf

@@ -21,8 +21,8 @@ namespace vf {
 
 bool unwrap_hot_supported(int h, int w);
 bool unwrap_batch_supported(int h, int w);
-void launch_unwrap_flood_batch(const uint16_t *rank16, const int32_t *seed, const uint32_t *inv, size_t inv_stride, int32_t *ppar, size_t gstride, int B, int h, int w,
-                               hipStream_t st);
+void launch_unwrap_flood_batch(const uint16_t *rank16, const int32_t *seed, const uint32_t *inv, size_t inv_stride, int32_t *ppar, size_t gstride,
+                               uint32_t *order, size_t ostride, int B, int h, int w, hipStream_t st);
 void launch_unwrap_flood_hot(const uint16_t *rank16, const int32_t *seed, const uint32_t *inv, size_t inv_stride, int32_t *ppar, size_t gstride,
                              int32_t *status, int B, int h, int w, hipStream_t st);
 
@@ -312,7 +312,8 @@ bool unwrap_ranked_supported(int h, int w)
 }
 
 // g0..g3: uint32 planes of gstride elements per frame (sort ping-pong); ppar: int32 plane of gstride elements
-void launch_unwrap_ranked(const float *quality, const uint8_t *mask, uint32_t *g0, uint32_t *g1, uint32_t *g2, uint32_t *g3,
+// returns true when the growth kernel also left its pop records in g0 (stride 2 * gstride per frame) for launch_unwrap_replay
+bool launch_unwrap_ranked(const float *quality, const uint8_t *mask, uint32_t *g0, uint32_t *g1, uint32_t *g2, uint32_t *g3,
                           int32_t *ppar, size_t gstride, uint16_t *rank16, int32_t *seed, int32_t *status, int B, int h, int w,
                           hipStream_t st, hipEvent_t ev_flood)
 {
@@ -328,17 +329,19 @@ void launch_unwrap_ranked(const float *quality, const uint8_t *mask, uint32_t *g
     static int use_hot = -1;
     if (use_hot < 0) { const char *e = getenv("VISTAF_FLOOD"); use_hot = (e && !strcmp(e, "scan")) ? 0 : (e && !strcmp(e, "hot")) ? 1 : 2; }
     if (use_hot == 2 && unwrap_batch_supported(h, w)) {
-        launch_unwrap_flood_batch(rank16, seed, g2, 2 * gstride, ppar, gstride, B, h, w, st);
-        return;
+        // the sort records in g0|g1 are dead once the ranks are out: the growth kernel logs its pops there
+        launch_unwrap_flood_batch(rank16, seed, g2, 2 * gstride, ppar, gstride, g0, 2 * gstride, B, h, w, st);
+        return true;
     }
     if (use_hot && unwrap_hot_supported(h, w)) {
         launch_unwrap_flood_hot(rank16, seed, g2, 2 * gstride, ppar, gstride, status, B, h, w, st);
-        return;
+        return false;
     }
     static bool attr_set = false;
     if (!attr_set) { hipFuncSetAttribute((const void *)k_unwrap_flood_ranked, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
     size_t lds = (size_t)((EN + 7) & ~7) * 2 + (size_t)cap * 4;
     hipLaunchKernelGGL(k_unwrap_flood_ranked, dim3(B), dim3(64), lds, st, rank16, seed, ppar, gstride, cap, status, h, w);
+    return false;
 }
 
 }  // namespace vf
