@@ -261,8 +261,147 @@ __global__ void k_chamfer_cols(const int32_t *__restrict__ g, float *__restrict_
     dist[b * (size_t)h * w + (size_t)y * w + x] = (float)best * (1.0f / 65536.0f);
 }
 
+// ---- the two-pass 3x3 chamfer itself (cv::distanceTransform DIST_L2, 3x3 mask: distanceTransform_3x3), one wave per frame.
+// Row y of the forward pass is  d(x) = min(t(x), d(x-1) + HV)  with  t(x) = 0 on a zero pixel, else
+// min(up-left + DG, up + HV, up-right + DG): t is data-parallel and the recurrence along the row is a min-plus
+// prefix scan, so a wave that holds PPL consecutive columns per lane does a row in a few dozen instructions
+// (lane-local scan, one DPP wave scan for the carries, one DPP shift for the neighbours across lanes).  The
+// backward pass is the mirror image.  Integer arithmetic throughout: results equal the sequential loops bit for
+// bit.  Rows are prefetched CH2_RING rows ahead (a single wave has nothing else to hide memory latency with).
+constexpr int CH2_INF = 0x7fffffff >> 2;     // cv DIST_MAX: border / initial value of the temporary plane
+constexpr int CH2_RING = 4;
+
+__device__ inline int ch2_shr1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }   // lane l <- l-1
+__device__ inline int ch2_shl1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); }   // lane l <- l+1
+// inclusive prefix minimum over lanes 0..l
+__device__ inline int ch2_scan_min_up(int v)
+{
+    const int big = 0x7fffffff;
+    int t;
+    t = __builtin_amdgcn_update_dpp(big, v, 0x111, 0xf, 0xf, false); v = t < v ? t : v;
+    t = __builtin_amdgcn_update_dpp(big, v, 0x112, 0xf, 0xf, false); v = t < v ? t : v;
+    t = __builtin_amdgcn_update_dpp(big, v, 0x114, 0xf, 0xf, false); v = t < v ? t : v;
+    t = __builtin_amdgcn_update_dpp(big, v, 0x118, 0xf, 0xf, false); v = t < v ? t : v;
+    t = __builtin_amdgcn_update_dpp(big, v, 0x142, 0xa, 0xf, false); v = t < v ? t : v;
+    t = __builtin_amdgcn_update_dpp(big, v, 0x143, 0xc, 0xf, false); v = t < v ? t : v;
+    return v;
+}
+
+template <int PPL>
+__global__ __launch_bounds__(64) void k_chamfer2(const uint8_t *__restrict__ src_all, int invert, int32_t *__restrict__ tmp_all,
+                                                 float *__restrict__ dist_all, int h, int w)
+{
+    const int lane = threadIdx.x;
+    const size_t b = blockIdx.x;
+    const size_t P = (size_t)h * w;
+    const uint8_t *src = src_all + b * P;
+    int32_t *tmp = tmp_all + b * P;
+    float *dist = dist_all + b * P;
+    const int x0 = lane * PPL;
+    const int step = CH_HV * PPL;
+
+    // ---- forward pass (top-left to bottom-right); the result plane goes to tmp
+    {
+        int up[PPL];
+#pragma unroll
+        for (int j = 0; j < PPL; j++) up[j] = CH2_INF;
+        uint8_t ring[CH2_RING][PPL];
+#pragma unroll
+        for (int r = 0; r < CH2_RING; r++)
+#pragma unroll
+            for (int j = 0; j < PPL; j++) ring[r][j] = (r < h && x0 + j < w) ? src[(size_t)r * w + x0 + j] : (uint8_t)0;
+        for (int y0 = 0; y0 < h; y0 += CH2_RING) {
+#pragma unroll
+            for (int r = 0; r < CH2_RING; r++) {
+                const int y = y0 + r;
+                if (y >= h) break;
+                const int upl = ch2_shr1(up[PPL - 1], CH2_INF), upr = ch2_shl1(up[0], CH2_INF);
+                int t[PPL];
+#pragma unroll
+                for (int j = 0; j < PPL; j++) {
+                    const bool in = x0 + j < w;
+                    const bool zero = in && (invert ? ring[r][j] != 0 : ring[r][j] == 0);
+                    const int a = (j > 0 ? up[j - 1] : upl) + CH_DG, c = (j < PPL - 1 ? up[j + 1] : upr) + CH_DG, u = up[j] + CH_HV;
+                    int m = a < u ? a : u;
+                    m = c < m ? c : m;
+                    t[j] = zero ? 0 : m;
+                }
+                // next row of the ring
+#pragma unroll
+                for (int j = 0; j < PPL; j++) ring[r][j] = (y + CH2_RING < h && x0 + j < w) ? src[(size_t)(y + CH2_RING) * w + x0 + j] : (uint8_t)0;
+                // d(x) = min(t(x), d(x-1) + HV): lane-local scan, carries across lanes by a wave scan of (last - step * lane)
+#pragma unroll
+                for (int j = 1; j < PPL; j++) { int v = t[j - 1] + CH_HV; t[j] = v < t[j] ? v : t[j]; }
+                const int sc = ch2_scan_min_up(t[PPL - 1] - step * lane) + step * lane;      // final value of this lane's last column
+                const int carry = ch2_shr1(sc, CH2_INF);                                     // d(x0 - 1)
+#pragma unroll
+                for (int j = 0; j < PPL; j++) {
+                    int v = carry + CH_HV * (j + 1);
+                    up[j] = v < t[j] ? v : t[j];
+                    if (x0 + j < w) tmp[(size_t)y * w + x0 + j] = up[j];
+                }
+            }
+        }
+    }
+    __threadfence_block();
+    // ---- backward pass (bottom-right to top-left)
+    {
+        int dn[PPL];
+#pragma unroll
+        for (int j = 0; j < PPL; j++) dn[j] = CH2_INF;
+        int ring[CH2_RING][PPL];
+#pragma unroll
+        for (int r = 0; r < CH2_RING; r++)
+#pragma unroll
+            for (int j = 0; j < PPL; j++) ring[r][j] = (h - 1 - r >= 0 && x0 + j < w) ? tmp[(size_t)(h - 1 - r) * w + x0 + j] : CH2_INF;
+        for (int y0 = 0; y0 < h; y0 += CH2_RING) {
+#pragma unroll
+            for (int r = 0; r < CH2_RING; r++) {
+                const int y = h - 1 - (y0 + r);
+                if (y < 0) break;
+                const int dnl = ch2_shr1(dn[PPL - 1], CH2_INF), dnr = ch2_shl1(dn[0], CH2_INF);
+                int t[PPL];
+#pragma unroll
+                for (int j = 0; j < PPL; j++) {
+                    const int a = (j < PPL - 1 ? dn[j + 1] : dnr) + CH_DG, c = (j > 0 ? dn[j - 1] : dnl) + CH_DG, u = dn[j] + CH_HV;
+                    int m = a < u ? a : u;
+                    m = c < m ? c : m;
+                    const int cur = x0 + j < w ? ring[r][j] : CH2_INF;
+                    t[j] = m < cur ? m : cur;
+                }
+#pragma unroll
+                for (int j = 0; j < PPL; j++) ring[r][j] = (y - CH2_RING >= 0 && x0 + j < w) ? tmp[(size_t)(y - CH2_RING) * w + x0 + j] : CH2_INF;
+                // d(x) = min(t(x), d(x+1) + HV): the same scan on mirrored lanes
+#pragma unroll
+                for (int j = PPL - 2; j >= 0; j--) { int v = t[j + 1] + CH_HV; t[j] = v < t[j] ? v : t[j]; }
+                // mirror: lane l' = 63 - l, so "lanes to the right" become a prefix
+                const int ml = 63 - lane;
+                int first = t[0] - step * ml;
+                // prefix minimum over mirrored lanes = suffix minimum over lanes: scan the value permuted to mirrored order
+                first = __builtin_amdgcn_ds_bpermute(ml << 2, first);
+                first = ch2_scan_min_up(first);
+                first = __builtin_amdgcn_ds_bpermute(ml << 2, first) + step * ml;            // final value of this lane's first column
+                const int carry = ch2_shl1(first, CH2_INF);                                  // d(x0 + PPL)
+#pragma unroll
+                for (int j = 0; j < PPL; j++) {
+                    int v = carry + CH_HV * (PPL - j);
+                    dn[j] = v < t[j] ? v : t[j];
+                    if (x0 + j < w) {
+                        int o = dn[j] > CH2_INF ? CH2_INF : dn[j];
+                        dist[(size_t)y * w + x0 + j] = (float)o * (1.0f / 65536.0f);
+                    }
+                }
+            }
+        }
+    }
+}
+
 void launch_chamfer(const uint8_t *src, bool invert, int32_t *rowdist, float *dist, int B, int h, int w, int cap_px, hipStream_t st)
 {
+    (void)cap_px;
+    if (w <= 256) { hipLaunchKernelGGL(k_chamfer2<4>, dim3(B), dim3(64), 0, st, src, invert ? 1 : 0, rowdist, dist, h, w); return; }
+    if (w <= 512) { hipLaunchKernelGGL(k_chamfer2<8>, dim3(B), dim3(64), 0, st, src, invert ? 1 : 0, rowdist, dist, h, w); return; }
+    // wider frames: closed form of the same two passes, exact up to cap_px (all that the callers look at)
     int rows = B * h;
     hipLaunchKernelGGL(k_rowdist, dim3((rows + 63) / 64), dim3(64), 0, st, src, invert ? 1 : 0, rowdist, h, w, B);
     int cap = (int)((cap_px + 2) / 0.955) + 2;
