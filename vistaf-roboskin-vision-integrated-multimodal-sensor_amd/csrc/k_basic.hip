@@ -88,22 +88,24 @@ __global__ void k_morph(const uint8_t *__restrict__ src, uint8_t *__restrict__ d
     if (x >= w) return;
     const uint8_t *s = src + b * (size_t)h * w;
     int r = se.k / 2;
-    int v = dilate ? 0 : 1;
+    // no early exit and clamped addresses: every load is independent of the others, so they are issued back to back
+    // instead of one memory round trip per element pixel
+    int any = 0, all = 1;
     for (int i = 0; i < se.k; i++) {
-        int yy = y + i - r;
-        if (yy < 0 || yy >= h) continue;
-        int x0 = x + se.lo[i], x1 = x + se.hi[i];
-        if (x0 < 0) x0 = 0;
-        if (x1 > w - 1) x1 = w - 1;
-        const uint8_t *row = s + (size_t)yy * w;
-        if (dilate) {
-            for (int xx = x0; xx <= x1; xx++) if (row[xx]) { v = 1; break; }
-            if (v) break;
-        } else {
-            for (int xx = x0; xx <= x1; xx++) if (!row[xx]) { v = 0; break; }
-            if (!v) break;
+        const int yy = y + i - r;
+        const bool rowin = yy >= 0 && yy < h;
+        const uint8_t *row = s + (size_t)(yy < 0 ? 0 : (yy >= h ? h - 1 : yy)) * w;
+        const int lo = se.lo[i], hi = se.hi[i];
+#pragma unroll 4
+        for (int dx = lo; dx <= hi; dx++) {
+            const int xx = x + dx;
+            const bool in = rowin && xx >= 0 && xx < w;
+            const uint8_t px = row[xx < 0 ? 0 : (xx >= w ? w - 1 : xx)];
+            any |= (in && px) ? 1 : 0;
+            all &= (!in || px) ? 1 : 0;
         }
     }
+    int v = dilate ? any : all;
     size_t p = (size_t)y * w + x;
     if (and_static && !and_static[p]) v = 0;
     if (and_frame && !and_frame[b * (size_t)h * w + p]) v = 0;
@@ -139,19 +141,25 @@ __global__ void k_morph_prefix(const uint16_t *__restrict__ inc, uint8_t *__rest
     if (x >= w) return;
     const uint16_t *I = inc + b * (size_t)h * w;
     int r = se.k / 2;
-    int v = dilate ? 0 : 1;
+    // no early exit: the 2 * k loads are independent, so they are all in flight together (one memory round trip
+    // per pixel instead of up to 2 * k dependent ones)
+    int any = 0, all = 1;
+#pragma unroll 8
     for (int i = 0; i < se.k; i++) {
         int yy = y + i - r;
-        if (yy < 0 || yy >= h) continue;
         int x0 = x + se.lo[i], x1 = x + se.hi[i];
         if (x0 < 0) x0 = 0;
         if (x1 > w - 1) x1 = w - 1;
-        if (x1 < x0) continue;
-        const uint16_t *row = I + (size_t)yy * w;
-        int cnt = (int)row[x1] - (x0 > 0 ? (int)row[x0 - 1] : 0);
-        if (dilate) { if (cnt > 0) { v = 1; break; } }
-        else { if (cnt != x1 - x0 + 1) { v = 0; break; } }
+        const bool valid = yy >= 0 && yy < h && x1 >= x0;
+        const int yc = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
+        const int x1c = x1 < 0 ? 0 : x1, x0c = x0 > 0 ? x0 - 1 : 0;
+        const uint16_t *row = I + (size_t)yc * w;
+        const int hi = (int)row[x1c], lo = (int)row[x0c];
+        const int cnt = hi - (x0 > 0 ? lo : 0);
+        any |= (valid && cnt > 0) ? 1 : 0;
+        all &= (!valid || cnt == x1 - x0 + 1) ? 1 : 0;
     }
+    int v = dilate ? any : all;
     size_t p = (size_t)y * w + x;
     if (and_static && !and_static[p]) v = 0;
     if (and_frame && !and_frame[b * (size_t)h * w + p]) v = 0;
