@@ -166,9 +166,75 @@ __global__ void k_morph_prefix(const uint16_t *__restrict__ inc, uint8_t *__rest
     dst[b * (size_t)h * w + p] = (uint8_t)v;
 }
 
+// Bit-plane variant for symmetric row spans [-a_i, a_i] (every cv ELLIPSE / RECT element): one workgroup per frame
+// packs the mask into 64-bit words with ballots (coalesced byte loads), dilates in LDS with word shifts -- a
+// 15x15 element costs a few hundred 64-bit ops per output word -- and unpacks.  Erosion is the dual: complement inside
+// the image, dilate, complement (out-of-image pixels never erode: cv::morphologyDefaultBorderValue).
+constexpr int MB_T = 256;
+__global__ __launch_bounds__(MB_T) void k_morph_bits(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int h, int w, RowSpanSE se,
+                                                     int dilate, const uint8_t *__restrict__ and_static, const uint8_t *__restrict__ and_frame)
+{
+    extern __shared__ unsigned long long mb_lds[];
+    const int W64 = (w + 63) >> 6, nw = h * W64;
+    unsigned long long *A = mb_lds, *O = mb_lds + nw;
+    const size_t b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint8_t *s = src + b * (size_t)h * w;
+    for (int y = wid; y < h; y += MB_T / 64)
+        for (int j = 0; j < W64; j++) {
+            int x = j * 64 + lane;
+            bool on = x < w && ((s[(size_t)y * w + x] != 0) == (dilate != 0));      // erode: complement inside the image
+            unsigned long long word = __ballot(on);
+            if (lane == 0) A[y * W64 + j] = word;
+        }
+    __syncthreads();
+    const int r = se.k / 2;
+    for (int t = tid; t < nw; t += MB_T) {
+        const int y = t / W64, j = t - y * W64;
+        unsigned long long acc = 0ull;
+        for (int i = 0; i < se.k; i++) {
+            const int yy = y + i - r, a = se.hi[i];
+            if (yy < 0 || yy >= h || a < 0) continue;
+            const unsigned long long *row = A + yy * W64;
+            const unsigned long long wc = row[j], wl = j > 0 ? row[j - 1] : 0ull, wr = j < W64 - 1 ? row[j + 1] : 0ull;
+            unsigned long long m = wc;
+            for (int dd = 1; dd <= a; dd++) m |= (wc >> dd) | (wr << (64 - dd)) | (wc << dd) | (wl >> (64 - dd));
+            acc |= m;
+        }
+        O[t] = acc;
+    }
+    __syncthreads();
+    uint8_t *o = dst + b * (size_t)h * w;
+    for (int y = wid; y < h; y += MB_T / 64)
+        for (int j = 0; j < W64; j++) {
+            int x = j * 64 + lane;
+            if (x >= w) continue;
+            size_t p = (size_t)y * w + x;
+            int v = (int)((O[y * W64 + j] >> lane) & 1ull);
+            if (!dilate) v ^= 1;
+            if (and_static && !and_static[p]) v = 0;
+            if (and_frame && !and_frame[b * (size_t)h * w + p]) v = 0;
+            o[p] = (uint8_t)v;
+        }
+}
+
+static bool morph_bits_ok(const RowSpanSE &se, int h, int w)
+{
+    for (int i = 0; i < se.k; i++) {
+        if (se.lo[i] > se.hi[i]) { if (se.hi[i] >= 0) return false; continue; }      // empty rows must read hi < 0
+        if (se.lo[i] != -se.hi[i] || se.hi[i] > 63) return false;
+    }
+    return (size_t)h * ((w + 63) >> 6) * 16 <= 64 * 1024;
+}
+
 void launch_morph(const uint8_t *src, uint8_t *dst, int B, int h, int w, const RowSpanSE &se, bool dilate,
                   const uint8_t *and_static, const uint8_t *and_frame, hipStream_t st, uint16_t *prefix_scratch)
 {
+    if (morph_bits_ok(se, h, w)) {
+        size_t lds = (size_t)h * ((w + 63) >> 6) * 16;
+        hipLaunchKernelGGL(k_morph_bits, dim3(B), dim3(MB_T), lds, st, src, dst, h, w, se, dilate ? 1 : 0, and_static, and_frame);
+        return;
+    }
     dim3 grid((w + 255) / 256, h, B);
     if (prefix_scratch && se.k >= 7 && w < 65536) {
         int rows = B * h;
