@@ -170,16 +170,18 @@ void preprocess(vistaf_ftp_handle *hd, const void *frames, int format, int B, hi
             int range = std::min(100, std::max(1, cv_round((double)c.bad_inpaint_radius)));   // cv::inpaint clamps the radius
             const uint8_t *seq_mask = hd->bad1;
             const int32_t *only = nullptr;
-            // default: LDS window kernel, whole-frame kernel for the frames it hands back.
-            // VISTAF_INPAINT=seq: whole-frame kernel only; =cluster: cluster-parallel front end
+            // default: the frame-window kernel (LDS-resident march), then the whole-frame kernel for the frames it hands back.
+            // VISTAF_INPAINT=cluster: first march every small independent cluster of hole pixels on its own window (pays off when
+            // the hole mask is many separate blobs; the fringe crests of this path form a few large clusters per frame, so it is off
+            // by default); =seq: whole-frame kernel only
             static int mode = -1;
-            if (mode < 0) { const char *ev = getenv("VISTAF_INPAINT"); mode = (ev && !strcmp(ev, "cluster")) ? 2 : (ev && !strcmp(ev, "seq")) ? 1 : 0; }
-            if (mode == 0) only = launch_inpaint_window(hd->img, hd->bad1, range, hd->inpaint_win_scratch, B, h, w, st);
-            if (mode == 2 && inpaint_clusters_supported(range)) {
+            if (mode < 0) { const char *ev = getenv("VISTAF_INPAINT"); mode = (ev && !strcmp(ev, "seq")) ? 1 : (ev && !strcmp(ev, "cluster")) ? 0 : 2; }
+            if (mode == 0 && inpaint_clusters_supported(range)) {
                 uint8_t *bad_big = nullptr;
                 launch_inpaint_clusters(hd->img, hd->bad1, range, hd->inpaint_cl_scratch, &bad_big, B, h, w, st);
-                seq_mask = bad_big;     // only clusters too large for an LDS window remain for the sequential kernel
+                seq_mask = bad_big;
             }
+            if (mode != 1) only = launch_inpaint_window(hd->img, seq_mask, range, hd->inpaint_win_scratch, B, h, w, st);
             launch_inpaint_telea(hd->img, seq_mask, range, hd->inpaint_scratch, hd->status, only, B, h, w, st);
         }
     } else if (timed) hipEventRecord(hd->ev[ST_INPAINT], st);

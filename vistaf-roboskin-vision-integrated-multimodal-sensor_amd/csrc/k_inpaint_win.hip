@@ -32,7 +32,7 @@ constexpr int WN_CELLS = 14464;     // window cells (9 B each: T f32, image f32,
 constexpr uint8_t W_KNOWN = 0, W_BAND = 1, W_INSIDE = 2, W_CHANGE = 3, W_ST = 3, W_BORDER = 0x10, W_ROW = 0x20, W_HOLE = 0x40, W_SEED = 0x80;
 
 __device__ unsigned long long g_win_dbg[1024][16];   // diagnostic shader-clock stamps per frame (VISTAF_TELEA_DBG)
-#define WSTAMP(i) do { if (lane == 0 && b < 1024) g_win_dbg[b][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define WSTAMP(i) do { if (!CL && lane == 0 && b < 1024) g_win_dbg[b][i] = __builtin_amdgcn_s_memtime(); } while (0)
 
 __device__ inline float wn_dpp_sum(float x)
 {
@@ -74,9 +74,10 @@ __global__ void k_bad_bbox(const uint8_t *__restrict__ bad, int32_t *__restrict_
 // word moves once.  A FMM push lands ~100 entries below the tail of a single sorted array; with the buffer the
 // amortised cost of a push is a handful of VALU ops plus ~1/64 of a merge.
 struct WQ {
-    unsigned long long *e;      // cold run, LDS [WN_QCAP]
+    unsigned long long *e;      // cold run, LDS [cap]
     uint32_t *hotL;             // LDS [64]: hot keys during a merge
     int head, tail, ovf;        // uniform
+    int cap;                    // capacity of e (power of two)
     int nh;                     // uniform: hot entries (lanes [0, nh), ascending)
     uint32_t h0;                // uniform: smallest hot key, 0xFFFFFFFF if none
     uint32_t hk, hv;            // per lane: hot key (0xFFFFFFFF = empty) / cell
@@ -89,13 +90,13 @@ __device__ __attribute__((always_inline)) inline void wq_init(WQ &q)
 __device__ __attribute__((always_inline)) inline void wq_prefetch(WQ &q)
 {
     // unconditional (a stale word is read when the run is empty; wq_pop checks head < tail before using it)
-    unsigned long long v = q.e[q.head & (WN_QCAP - 1)];
+    unsigned long long v = q.e[q.head & (q.cap - 1)];
     q.preT = (uint32_t)(v >> 32); q.preI = (uint32_t)v;
 }
 __device__ __attribute__((always_inline)) inline void wq_merge(WQ &q, int lane)
 {
     int n = q.tail - q.head;
-    if (q.tail + 64 > WN_QCAP) {
+    if (q.tail + 64 > q.cap) {
         if (q.head == 0) { q.ovf = 1; q.nh = 0; q.hk = 0xFFFFFFFFu; q.h0 = 0xFFFFFFFFu; return; }
         for (int j0 = 0; j0 < n; j0 += 64) {                // slide the cold run back to 0 (ascending chunks never clobber unread words)
             int j = j0 + lane;
@@ -208,28 +209,22 @@ __device__ inline int wn_next_seed(const uint8_t *f, int cells, int &base, unsig
     return p;
 }
 
-__global__ __launch_bounds__(64) void k_telea_window(float *__restrict__ img_all, const uint8_t *__restrict__ bad_all,
-                                                     const int32_t *__restrict__ box, int32_t *__restrict__ fb, int range, int B, int h, int w)
+// The march on one window.  CL = false: the window holds every hole pixel of the frame (lab / rootp unused).
+// CL = true: only the hole pixels of the cluster `rootp` (label plane `lab`) are INSIDE; hole pixels of other
+// clusters that happen to lie in the window are treated as known pixels -- they are farther than range + 1 from
+// every pixel this march reads, and they are restored by their own march.  Returns false when the queue overflowed
+// (nothing has been written back).
+template <bool CL>
+__device__ inline bool wn_march(float *__restrict__ img, const uint8_t *__restrict__ bad, const int32_t *__restrict__ lab, int rootp,
+                                int i0, int j0, int wh, int ww, int range, int h, int w, unsigned char *lds, int cells_cap, int qcap,
+                                int lane, int b)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char wn_lds[];
-    unsigned long long *qe = (unsigned long long *)wn_lds;       // [WN_QCAP]
-    float *t = (float *)(qe + WN_QCAP);                          // [WN_CELLS]
-    float *im = t + WN_CELLS;                                    // [WN_CELLS]
-    uint8_t *f = (uint8_t *)(im + WN_CELLS);                     // [WN_CELLS]
-    uint32_t *hotL = (uint32_t *)(f + WN_CELLS);                 // [64]
-    const int lane = threadIdx.x;
-    const int b = blockIdx.x;
-    const int P = h * w;
-    const int xmin = box[b], ymin = box[B + b], xmax = box[2 * B + b], ymax = box[3 * B + b];
-    if (xmin == 0x7f7f7f7f) return;                              // no hole pixel: nothing to inpaint
-    const int M = range + 1;
-    // window in padded frame coordinates [i0, i1] x [j0, j1], not clipped (cells beyond the image: BORDER)
-    const int i0 = ymin + 1 - M, i1 = ymax + 1 + M;
-    const int j0 = xmin + 1 - M, j1 = xmax + 1 + M;
-    const int wh = i1 - i0 + 1, ww = j1 - j0 + 1, cells = wh * ww;
-    if (cells > WN_CELLS) { if (lane == 0) fb[b] = 1; return; }
-    float *img = img_all + (size_t)b * P;
-    const uint8_t *bad = bad_all + (size_t)b * P;
+    unsigned long long *qe = (unsigned long long *)lds;          // [qcap]
+    float *t = (float *)(qe + qcap);                             // [cells_cap]
+    float *im = t + cells_cap;                                   // [cells_cap]
+    uint8_t *f = (uint8_t *)(im + cells_cap);                    // [cells_cap]
+    uint32_t *hotL = (uint32_t *)(f + cells_cap);                // [64]
+    const int cells = wh * ww;
     WSTAMP(0);
 
     // ---- load window: hole / border bits, T = 1e6, image
@@ -243,6 +238,7 @@ __global__ __launch_bounds__(64) void k_telea_window(float *__restrict__ img_all
             size_t gp = interior ? (size_t)(gi - 1) * w + (gj - 1) : 0;
             float v = img[gp];
             uint8_t bd = bad[gp];
+            if (CL) bd = (bd && lab[gp] == rootp) ? 1 : 0;
             int li = r * ww + cc;
             im[li] = interior ? v : 0.f;
             f[li] = !interior ? W_BORDER : bd ? W_HOLE : (uint8_t)0;
@@ -279,7 +275,7 @@ __global__ __launch_bounds__(64) void k_telea_window(float *__restrict__ img_all
 
     WSTAMP(2);
     WQ q;
-    q.e = qe; q.hotL = hotL; q.ovf = 0;
+    q.e = qe; q.hotL = hotL; q.ovf = 0; q.cap = qcap;
     wq_init(q);
     unsigned long long np1 = 0, np2 = 0, nfill = 0;
     // ---- pass 1: outside T field (icvCalcFMM, negate); seeds pop first in raster order, then the queue.
@@ -449,8 +445,8 @@ __global__ __launch_bounds__(64) void k_telea_window(float *__restrict__ img_all
         }
     }
     WSTAMP(7);
-    if (lane == 0 && b < 1024) { g_win_dbg[b][8] = (np1 << 32) | np2; g_win_dbg[b][9] = (nfill << 32) | (unsigned)cells; }
-    if (q.ovf) { if (lane == 0) fb[b] = 1; return; }
+    if (!CL && lane == 0 && b < 1024) { g_win_dbg[b][8] = (np1 << 32) | np2; g_win_dbg[b][9] = (nfill << 32) | (unsigned)cells; }
+    if (q.ovf) return false;
     // ---- write back the hole pixels
     for (int r = 0; r < wh; r++) {
         const int gi = i0 + r;
@@ -459,6 +455,71 @@ __global__ __launch_bounds__(64) void k_telea_window(float *__restrict__ img_all
             if (f[li] & W_HOLE) img[(size_t)(gi - 1) * w + (j0 + cc - 1)] = im[li];
         }
     }
+    return true;
+}
+
+__global__ __launch_bounds__(64) void k_telea_window(float *__restrict__ img_all, const uint8_t *__restrict__ bad_all,
+                                                     const int32_t *__restrict__ box, int32_t *__restrict__ fb, int range, int B, int h, int w)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char wn_lds[];
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;
+    const int P = h * w;
+    const int xmin = box[b], ymin = box[B + b], xmax = box[2 * B + b], ymax = box[3 * B + b];
+    if (xmin == 0x7f7f7f7f) return;                              // no hole pixel: nothing to inpaint
+    const int M = range + 1;
+    // window in padded frame coordinates [i0, i1] x [j0, j1], not clipped (cells beyond the image: BORDER)
+    const int i0 = ymin + 1 - M, i1 = ymax + 1 + M;
+    const int j0 = xmin + 1 - M, j1 = xmax + 1 + M;
+    const int wh = i1 - i0 + 1, ww = j1 - j0 + 1;
+    bool ok = wh * ww <= WN_CELLS;
+    if (ok) ok = wn_march<false>(img_all + (size_t)b * P, bad_all + (size_t)b * P, nullptr, 0, i0, j0, wh, ww, range, h, w, wn_lds, WN_CELLS, WN_QCAP, lane, b);
+    if (!ok && lane == 0) fb[b] = 1;
+}
+
+// Cluster front end: hole pixels farther apart than 2 * range + 3 never interact (rings and neighbourhoods reach
+// range + 1), so every connected component of the hole mask dilated by a (2 * (range + 1) + 1)^2 square -- a CLUSTER --
+// can be marched on its own small window with its own queue, in exactly the order the whole-frame queue would
+// pop its pixels.  One wave per cluster, several clusters per CU: the batch turns from B sequential marches into
+// thousands of short ones.  Clusters whose window or queue does not fit are flagged in big[] and left to
+// k_telea_window, which then sees only their pixels.
+constexpr int CL2_CELLS = 3072;     // window cells per cluster
+constexpr int CL2_QCAP = 512;       // queue entries per cluster
+constexpr int CL2_SLOTS = 48;       // workgroups per frame (each walks clusters c, c + CL2_SLOTS, ...)
+
+__global__ __launch_bounds__(64) void k_telea_clusters2(float *__restrict__ img_all, const uint8_t *__restrict__ bad_all,
+                                                        const int32_t *__restrict__ labels_all, const int32_t *__restrict__ list_all,
+                                                        const int32_t *__restrict__ count, const int32_t *__restrict__ xmin,
+                                                        const int32_t *__restrict__ ymin, const int32_t *__restrict__ xmax,
+                                                        const int32_t *__restrict__ ymax, uint8_t *__restrict__ big, int range, int h, int w)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char wn_lds[];
+    const int lane = threadIdx.x;
+    const size_t b = blockIdx.y;
+    const int P = h * w;
+    const int ncl = count[b];
+    const int M = range + 1;
+    for (int c = blockIdx.x; c < ncl; c += gridDim.x) {
+        const int rootp = list_all[b * (size_t)P + c];
+        const size_t root = b * (size_t)P + rootp;
+        const int i0 = ymin[root] + 1 - M, i1 = ymax[root] + 1 + M;
+        const int j0 = xmin[root] + 1 - M, j1 = xmax[root] + 1 + M;
+        const int wh = i1 - i0 + 1, ww = j1 - j0 + 1;
+        bool ok = wh * ww <= CL2_CELLS;
+        if (ok) ok = wn_march<true>(img_all + b * (size_t)P, bad_all + b * (size_t)P, labels_all + b * (size_t)P, rootp, i0, j0, wh, ww, range, h, w,
+                                    wn_lds, CL2_CELLS, CL2_QCAP, lane, 0);
+        if (!ok && lane == 0) big[root] = 1;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+int inpaint_cluster_cells_cap() { return CL2_CELLS; }
+
+void launch_telea_clusters2(float *img, const uint8_t *bad, const int32_t *labels, const int32_t *list, const int32_t *count, const int32_t *xmin,
+                            const int32_t *ymin, const int32_t *xmax, const int32_t *ymax, uint8_t *big, int range, int B, int h, int w, hipStream_t st)
+{
+    const size_t lds = (size_t)CL2_CELLS * 9 + (size_t)CL2_QCAP * 8 + 256;
+    hipLaunchKernelGGL(k_telea_clusters2, dim3(CL2_SLOTS, B), dim3(64), lds, st, img, bad, labels, list, count, xmin, ymin, xmax, ymax, big, range, h, w);
 }
 
 void telea_window_debug_dump(int B)
