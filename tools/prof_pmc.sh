@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_${tag}_$c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_${tag}_$c.log 2>&1
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_${tag}_$c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --inflight 1 > $R/gpurun_out/pmc_${tag}_$c.log 2>&1
   echo pmc_${c}_exit=$?
 done
 python3 - $R/gpurun_out $tag <<'PY'

@@ -30,7 +30,7 @@ struct GKern { float *d = nullptr; int k = 0; };
 
 enum Stage { ST_GRAY_BAD = 0, ST_INPAINT, ST_PREPROC, ST_DEMOD, ST_RELIABLE, ST_UNWRAP_RANK, ST_UNWRAP, ST_UNWRAP_TREE, ST_DETREND, ST_SMOOTH_FLIP, ST_COMPOSE, ST_MM_BLOB,
              ST_TAIL, ST_COUNT };
-const char *kStageNames[ST_COUNT] = {"gray+badpix", "inpaint (k_telea)", "illum+blur+apod+median", "pruned-dft demod", "reliable mask",
+const char *kStageNames[ST_COUNT] = {"gray+badpix", "inpaint (k_telea_window)", "illum+blur+apod+median", "pruned-dft demod", "reliable mask",
                                      "unwrap rank (k_unwrap_rank)", "unwrap flood (k_unwrap_flood_batch)", "unwrap tree", "detrend (3x IRLS)", "smooth+flip", "frontier+compose", "mm+blob filter", "tail"};
 
 int cv_round(double v) { return (int)std::nearbyint(v); }
@@ -165,8 +165,8 @@ void preprocess(vistaf_ftp_handle *hd, const void *frames, int format, int B, hi
             for (int it = 0; it < c.bad_dilate_iters; it++) { launch_morph(src, dst, B, h, w, hd->se_bad, true, nullptr, nullptr, st); std::swap(src, dst); }
         if (src != hd->bad1) hipMemcpyAsync(hd->bad1, src, (size_t)B * P, hipMemcpyDeviceToDevice, st);
         launch_count_u8(hd->bad1, hd->bad_count, B, P, st);
-        if (timed) hipEventRecord(hd->ev[ST_INPAINT], st);
         {
+            bool ev_done = false;
             int range = std::min(100, std::max(1, cv_round((double)c.bad_inpaint_radius)));   // cv::inpaint clamps the radius
             const uint8_t *seq_mask = hd->bad1;
             const int32_t *only = nullptr;
@@ -181,7 +181,8 @@ void preprocess(vistaf_ftp_handle *hd, const void *frames, int format, int B, hi
                 launch_inpaint_clusters(hd->img, hd->bad1, range, hd->inpaint_cl_scratch, &bad_big, B, h, w, st);
                 seq_mask = bad_big;
             }
-            if (mode != 1) only = launch_inpaint_window(hd->img, seq_mask, range, hd->inpaint_win_scratch, B, h, w, st);
+            if (timed && mode != 2) { hipEventRecord(hd->ev[ST_INPAINT], st); ev_done = true; }
+            if (mode != 1) only = launch_inpaint_window(hd->img, seq_mask, range, hd->inpaint_win_scratch, B, h, w, st, (timed && !ev_done) ? hd->ev[ST_INPAINT] : nullptr);
             launch_inpaint_telea(hd->img, seq_mask, range, hd->inpaint_scratch, hd->status, only, B, h, w, st);
         }
     } else if (timed) hipEventRecord(hd->ev[ST_INPAINT], st);

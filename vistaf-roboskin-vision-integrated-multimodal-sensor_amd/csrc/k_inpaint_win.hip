@@ -543,7 +543,7 @@ void telea_window_debug_dump(int B)
 size_t inpaint_win_scratch_bytes(int B) { return (size_t)B * 5 * sizeof(int32_t) + 256; }
 
 // box scratch: [4][B] bbox planes + [B] fallback flags.  Returns the device pointer of the fallback flags.
-int32_t *launch_inpaint_window(float *img, const uint8_t *bad, int range, void *scratch, int B, int h, int w, hipStream_t st)
+int32_t *launch_inpaint_window(float *img, const uint8_t *bad, int range, void *scratch, int B, int h, int w, hipStream_t st, hipEvent_t ev_march)
 {
     int32_t *box = (int32_t *)scratch, *fb = box + 4 * (size_t)B;
     (void)hipMemsetAsync(box, 0x7f, (size_t)B * 8, st);
@@ -553,6 +553,7 @@ int32_t *launch_inpaint_window(float *img, const uint8_t *bad, int range, void *
     const size_t lds = (size_t)WN_CELLS * 9 + (size_t)WN_QCAP * 8 + 256;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_telea_window, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    if (ev_march) (void)hipEventRecord(ev_march, st);     // stage timing: the march starts here (the bbox pass belongs to the mask stage)
     hipLaunchKernelGGL(k_telea_window, dim3(B), dim3(64), lds, st, img, bad, box, fb, range, B, h, w);
     return fb;
 }

@@ -60,7 +60,8 @@ void launch_inpaint_telea(float *img, const uint8_t *bad, int range, void *scrat
 
 // ---- k_inpaint_win.hip (LDS-resident window kernel; returns the per-frame fallback flags for launch_inpaint_telea)
 size_t inpaint_win_scratch_bytes(int B);
-int32_t *launch_inpaint_window(float *img, const uint8_t *bad, int range, void *scratch, int B, int h, int w, hipStream_t st);
+int32_t *launch_inpaint_window(float *img, const uint8_t *bad, int range, void *scratch, int B, int h, int w, hipStream_t st,
+                               hipEvent_t ev_march = nullptr);
 
 // ---- k_inpaint_cl.hip (cluster-parallel front end; leaves oversized clusters in *bad_big_out) ----------
 size_t inpaint_cl_scratch_bytes_per_frame(int h, int w);
