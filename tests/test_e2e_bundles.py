@@ -108,3 +108,35 @@ def test_hip_path_reproduces_reference_bundle_on_real_photo(pkg):
     bad = diff > 1e-4 * peak
     assert bad.sum() <= 1e-3 * N * N and float(diff.max()) <= 20e-4 * peak      # same robust rule as test_native_size_1182_as_shipped
     assert int((rel != o["output_reliable_crop"]).sum()) <= 2e-4 * N * N
+
+
+@pytest.mark.gpu
+def test_written_bundle_and_result_match_the_stored_ones(pkg, tmp_path):
+    """N1 on the real pair: predict -> masks -> height_map_bundle.npz / result.json, diffed key by key against what the
+    reference stored for FINAL_E (bundle masks from the fixture, scalars from its result.json)."""
+    fx = _fixture()
+    cal, neg = pkg.load_calibration(os.path.join(G, "calibration_phase_to_height.json"))
+    fcal = pkg.load_force_calibration(os.path.join(G, "calibration_height_to_force.json"))
+    sensor = pkg.FtpSensor(fx["ref"], fx["circle"], pkg.FtpConfig.as_shipped(), cal, neg, fcal["best_model"], max_batch=1)
+    res = sensor.predict(fx["def"])
+    assert res is not None
+    masks = sensor.masks(0)
+    cx, cy, r = fx["circle"]
+    bundle = pkg.height_map_bundle(res["height_map_mm_crop"], masks, (1421, 538, 2603, 1720), (2160, 3840), (2012, 1129, 591), (cx, cy, r))
+    paths = pkg.export_heightmap_files(str(tmp_path), bundle, save_crop_csv=False)
+    z = np.load(paths["bundle_npz"])
+    assert len(z.files) == 2 + 7 + 7 + 10
+    assert z["height_full"].shape == (2160, 3840) and int(z["meta_roi_radius_crop"]) == 590
+    for key, ref_mask, thr in (("crop_reliable", fx["reliable"], 0.9999), ("crop_output_reliable", fx["output_reliable"], 0.9999),
+                               ("crop_contact_dilated", fx["contact_dilated"], 0.998), ("crop_contact_kept_by_depth", fx["contact_kept"], 0.999)):
+        assert _iou(z[key], ref_mask) >= thr, key
+    assert not z["crop_hole_candidates"].any()
+    assert np.array_equal(z["crop_roi_eroded"], np.isfinite(fx["height"]))             # NaN outside the eroded ROI upstream too
+    stored = json.load(open(os.path.join(G, "ref_tail_demos.json")))["demos"]["FINAL_E_deformed"]["stored"]
+    rec = pkg.result_record(res, fcal["best_model"], "./Force/FINAL_reference.jpg", "./Final_demos_images/FINAL_E_deformed.jpg", "o", "o/ftp_run")
+    assert abs(rec["estimated_grating_period_px"] - stored["estimated_grating_period_px"]) <= 1e-4 * stored["estimated_grating_period_px"]
+    assert abs(rec["mm_per_px"] - stored["mm_per_px"]) <= 1e-4 * stored["mm_per_px"]
+    assert abs(rec["max_depth_mm"] - stored["max_depth_mm"]) <= 2e-4 * stored["max_depth_mm"]
+    assert abs(rec["contact_area_mm2"] - stored["contact_area_mm2"]) <= 2e-3 * stored["contact_area_mm2"]
+    assert abs(rec["volume_cm3"] - stored["volume_cm3"]) <= 2e-3 * stored["volume_cm3"]
+    assert abs(rec["force_N"] - stored["force_N"]) <= 5e-3 * stored["force_N"]

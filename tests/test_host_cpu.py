@@ -148,3 +148,52 @@ def test_two_rank_all_gather_gloo(pkg):
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def test_result_writers_match_reference_schema(pkg, tmp_path):
+    """N1: result.json / result.csv / height_map_bundle.npz carry the reference's keys, order and dtypes
+    (Code/force_sensor.py:242-295, Code/shape_ftp.py:292-309); checked against the stored demo artefacts' schema recorded in
+    tests/golden/ref_tail_demos.json and against the bundle key list of SURVEY.md §3."""
+    import csv
+    n = 32
+    rng = np.random.default_rng(0)
+    height = rng.uniform(0, 1, (n, n)).astype(np.float32)
+    height[:4] = np.nan
+    res = {"estimated_grating_period_px": 65.83619546657023, "mm_per_px": 0.030378426119953176, "volume_cm3": 0.11378655442935222,
+           "contact_area_mm2": 304.914771865451, "max_depth_mm": 1.1214957237243652, "force_N": 3.2960528395288056}
+    fm = pkg.load_force_calibration(os.path.join(G, "calibration_height_to_force.json"))["best_model"]
+    rec = pkg.result_record(res, fm, "./Force/FINAL_reference.jpg", "./Final_demos_images/FINAL_E_deformed.jpg", "out", "out/ftp_run")
+    assert list(rec.keys()) == ["reference_path", "deformed_path", "output_dir", "ftp_output_dir", "grating_pitch_mm", "depth_eps_mm",
+                                "estimated_grating_period_px", "mm_per_px", "volume_cm3", "contact_area_mm2", "max_depth_mm", "force_N",
+                                "force_model"]
+    assert list(rec["force_model"].keys()) == ["type", "params", "equation", "rmse", "r2"]
+    jp = pkg.write_result_json(str(tmp_path), rec)
+    back = json.load(open(jp))
+    assert back == json.loads(json.dumps(rec)) and open(jp).read().startswith('{\n  "reference_path"')       # indent=2 as upstream
+    # the stored FINAL_E result.json values survive the round trip digit for digit
+    stored = json.load(open(os.path.join(G, "ref_tail_demos.json")))["demos"]["FINAL_E_deformed"]["stored"]
+    for k in ("volume_cm3", "contact_area_mm2", "max_depth_mm", "force_N", "mm_per_px", "estimated_grating_period_px", "depth_eps_mm"):
+        assert back[k] == stored[k]
+    cp = pkg.write_result_csv(str(tmp_path), rec)
+    rows = list(csv.reader(open(cp)))
+    assert rows[0] == ["reference_path", "deformed_path", "volume_cm3", "force_N", "contact_area_mm2", "max_depth_mm", "mm_per_px",
+                       "estimated_grating_period_px", "ftp_output_dir", "force_model_type"]
+    assert rows[1][-1] == fm["type"] and float(rows[1][2]) == res["volume_cm3"]
+    masks = {k: rng.random((n, n)) > 0.5 for k in ("roi_eroded", "reliable", "output_reliable", "circ_mask", "contact_kept_by_depth",
+                                                   "hole_candidates", "contact_dilated")}
+    b = pkg.height_map_bundle(height, masks, (10, 20, 10 + n, 20 + n), (100, 120), (26, 36, 15), (16, 16, 15))
+    keys = list(b.keys())
+    assert keys[:2] == ["height_crop", "height_full"]
+    assert keys[2:9] == ["crop_" + k for k in masks] and keys[9:16] == ["full_" + k for k in masks]
+    assert keys[16:] == ["meta_crop_x1", "meta_crop_y1", "meta_crop_x2", "meta_crop_y2", "meta_roi_center_x_full", "meta_roi_center_y_full",
+                         "meta_roi_radius_full", "meta_roi_center_x_crop", "meta_roi_center_y_crop", "meta_roi_radius_crop"]
+    assert b["height_full"].shape == (100, 120) and b["height_full"].dtype == np.float32 and np.isnan(b["height_full"][0, 0])
+    assert np.array_equal(b["height_full"][20:20 + n, 10:10 + n], height, equal_nan=True)
+    assert b["full_reliable"].dtype == bool and np.array_equal(b["full_reliable"][20:20 + n, 10:10 + n], masks["reliable"])
+    assert b["meta_crop_x1"].dtype == np.int32 and b["meta_crop_x1"].shape == ()
+    paths = pkg.export_heightmap_files(str(tmp_path), b)
+    z = np.load(paths["bundle_npz"])
+    assert sorted(z.files) == sorted(keys) and np.array_equal(z["height_crop"], height, equal_nan=True)
+    assert np.array_equal(np.load(paths["crop_npy"]), height, equal_nan=True)
+    first = open(paths["crop_csv"]).readline().strip().split(",")
+    assert len(first) == n and first[0] == "nan"

@@ -211,6 +211,7 @@ class FtpSensor:
             _lib.check(self._lib.vistaf_ftp_predict_batch(
                 self._h, t.data_ptr(), self._format_of(t), b, out["height_map_mm"].data_ptr(), out["output_reliable"].data_ptr(),
                 out["scalars"].data_ptr(), out["status"].data_ptr(), _stream_ptr(self.device)))
+        self._last_out = out
         return out
 
     def intermediate(self, name: str, batch: int, dtype=torch.float32) -> torch.Tensor:
@@ -224,6 +225,27 @@ class FtpSensor:
                                                              _stream_ptr(self.device)))
         torch.cuda.synchronize(self.device)
         return buf.view(dtype)
+
+    def masks(self, index: int = 0) -> Dict[str, np.ndarray]:
+        """The seven boolean crop masks of frame `index` of the last predict_batch, under the names the reference stores
+        them with in height_map_bundle.npz (Code/shape_ftp.py:1898-1906)."""
+        last = getattr(self, "_last_out", None)
+        if last is None:
+            raise RuntimeError("masks() needs a previous predict_batch")
+        batch = int(last["status"].shape[0])
+
+        def plane(name):
+            return self.intermediate(name, batch, torch.uint8).view(batch, self.h, self.w)[index].cpu().numpy().astype(bool)
+        roi = self.intermediate("roi", 1, torch.uint8).view(self.h, self.w).cpu().numpy().astype(bool)
+        cx, cy, r = self.roi_circle
+        yy, xx = np.ogrid[:self.h, :self.w]
+        circ = ((xx - cx) ** 2 + (yy - cy) ** 2) <= r * r                                   # create_circular_mask (:437-440)
+        reliable = plane("reliable")
+        return {
+            "roi_eroded": roi, "reliable": reliable, "output_reliable": last["output_reliable"][index].cpu().numpy().astype(bool), "circ_mask": circ,
+            "contact_kept_by_depth": plane("kept"), "hole_candidates": np.zeros((self.h, self.w), dtype=bool),
+            "contact_dilated": plane("contact_d"),
+        }
 
     def enable_stage_timing(self, enable: bool = True):
         _lib.check(self._lib.vistaf_ftp_enable_stage_timing(self._h, int(enable)))
