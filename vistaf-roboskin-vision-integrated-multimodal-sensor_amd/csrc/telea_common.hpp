@@ -1,0 +1,350 @@
+// Shared pieces of the LDS-resident Telea march (k_inpaint_win.hip, k_inpaint_mw.hip): flag byte layout, DPP helpers, the
+// two-run stable priority queue, the FMM quadrant solve and the raster seed scan.
+#pragma once
+#include "kernels.hpp"
+
+namespace vf {
+
+// flag byte: bits 0-1 state, bit 4 outside the image, bit 5 scratch (hole in row range), bit 6 hole pixel,
+// bit 7 seed (initial band)
+constexpr uint8_t W_KNOWN = 0, W_BAND = 1, W_INSIDE = 2, W_CHANGE = 3, W_ST = 3, W_BORDER = 0x10, W_ROW = 0x20, W_HOLE = 0x40, W_SEED = 0x80;
+
+__device__ inline float wn_dpp_sum(float x)
+{
+    int v = __float_as_int(x);
+#define VF_ADD(ctrl, rm)                                                                          \
+    v = __float_as_int(__int_as_float(v) + __int_as_float(__builtin_amdgcn_update_dpp(0, v, ctrl, rm, 0xf, false)));
+    VF_ADD(0xB1, 0xf) VF_ADD(0x4E, 0xf) VF_ADD(0x141, 0xf) VF_ADD(0x140, 0xf) VF_ADD(0x142, 0xa) VF_ADD(0x143, 0xc)
+#undef VF_ADD
+    return __int_as_float(__builtin_amdgcn_readlane(v, 63));
+}
+__device__ inline float wn_lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+// Stable priority queue (T, push order), the semantics of OpenCV's CvPriorityQueueFloat.  Two sorted runs:
+//   * COLD: a sorted array of (T bits << 32 | cell) words in LDS, popped at its head;
+//   * HOT: the newest <= 64 pushes, sorted, one per lane in registers.  A push is a branch-free insertion
+//     (one DPP shift of the lanes holding larger keys); nothing in LDS moves.
+// Every hot entry is younger than every cold entry, so "cold first on equal T" is FIFO.  When the hot run is full
+// it is merged into the cold array: each hot lane binary-searches its slot (after the cold entries with
+// T' <= T), each cold entry above the smallest hot key binary-searches how many hot keys precede it, and every
+// word moves once.  A FMM push lands ~100 entries below the tail of a single sorted array; with the buffer the
+// amortised cost of a push is a handful of VALU ops plus ~1/64 of a merge.
+struct WQ {
+    unsigned long long *e;      // cold run, LDS [cap]
+    uint32_t *hotL;             // LDS [64]: hot keys during a merge
+    int head, tail, ovf;        // uniform
+    int cap;                    // capacity of e (power of two)
+    int nh;                     // uniform: hot entries (lanes [0, nh), ascending)
+    uint32_t h0;                // uniform: smallest hot key, 0xFFFFFFFF if none
+    uint32_t hk, hv;            // per lane: hot key (0xFFFFFFFF = empty) / cell
+    uint32_t preT, preI;        // per lane copy of the cold head entry (valid while head < tail)
+};
+__device__ __attribute__((always_inline)) inline void wq_init(WQ &q)
+{
+    q.head = q.tail = 0; q.nh = 0; q.h0 = 0xFFFFFFFFu; q.hk = 0xFFFFFFFFu; q.hv = 0; q.preT = 0xFFFFFFFFu; q.preI = 0;
+}
+__device__ __attribute__((always_inline)) inline void wq_prefetch(WQ &q)
+{
+    // unconditional (a stale word is read when the run is empty; wq_pop checks head < tail before using it)
+    unsigned long long v = q.e[q.head & (q.cap - 1)];
+    q.preT = (uint32_t)(v >> 32); q.preI = (uint32_t)v;
+}
+__device__ __attribute__((always_inline)) inline void wq_merge(WQ &q, int lane)
+{
+    int n = q.tail - q.head;
+    if (q.tail + 64 > q.cap) {
+        if (q.head == 0) { q.ovf = 1; q.nh = 0; q.hk = 0xFFFFFFFFu; q.h0 = 0xFFFFFFFFu; return; }
+        for (int j0 = 0; j0 < n; j0 += 64) {                // slide the cold run back to 0 (ascending chunks never clobber unread words)
+            int j = j0 + lane;
+            unsigned long long v = 0;
+            if (j < n) v = q.e[j + q.head];
+            __builtin_amdgcn_wave_barrier();
+            if (j < n) q.e[j] = v;
+            __builtin_amdgcn_wave_barrier();
+        }
+        q.head = 0; q.tail = n;
+    }
+    const unsigned long long *ce = q.e + q.head;
+    q.hotL[lane] = q.hk;
+    // slot of hot lane i: after the c cold entries with T' <= key
+    int lo = 0, hi = n;
+    const int it1 = n > 0 ? 32 - __builtin_clz((unsigned)n) : 0;     // ceil(log2(n + 1))
+    for (int it = 0; it < it1; it++) {
+        int mid = (lo + hi) >> 1;
+        bool act = lo < hi;
+        uint32_t tm = act ? (uint32_t)(ce[mid] >> 32) : 0u;
+        if (act) { if (tm <= q.hk) lo = mid + 1; else hi = mid; }
+    }
+    const int c = lo;
+    const int c0 = __builtin_amdgcn_readfirstlane(c);        // cold entries below c0 stay where they are
+    __builtin_amdgcn_wave_barrier();
+    for (int jt = n - 1; jt >= c0; jt -= 64) {               // top-down: an entry moves up by <= 64
+        const int j = jt - lane;
+        const bool act = j >= c0;
+        const unsigned long long v = act ? ce[j] : 0ull;
+        const uint32_t tj = (uint32_t)(v >> 32);
+        int l2 = 0, h2 = 64;                                  // s = hot keys < tj
+#pragma unroll
+        for (int it = 0; it < 7; it++) {
+            int mid = (l2 + h2) >> 1;
+            bool a2 = l2 < h2;
+            uint32_t km = q.hotL[a2 ? mid : 0];
+            if (a2) { if (km < tj) l2 = mid + 1; else h2 = mid; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (act) q.e[q.head + j + l2] = v;
+        __builtin_amdgcn_wave_barrier();
+    }
+    q.e[q.head + c + lane] = ((unsigned long long)q.hk << 32) | q.hv;
+    __builtin_amdgcn_wave_barrier();
+    q.tail += 64;
+    q.nh = 0; q.hk = 0xFFFFFFFFu; q.h0 = 0xFFFFFFFFu;
+    wq_prefetch(q);
+}
+__device__ __attribute__((always_inline)) inline void wq_push(WQ &q, float Tf, int idx, int lane)
+{
+    if (q.nh == 64) { wq_merge(q, lane); if (q.ovf) return; }
+    const uint32_t tb = __float_as_uint(Tf);
+    const uint32_t pk = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q.hk, 0x138, 0xf, 0xf, false);    // wave_shr1: lane l <- l-1, lane 0 <- 0
+    const uint32_t pv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q.hv, 0x138, 0xf, 0xf, false);
+    const bool gt = q.hk > tb, pgt = pk > tb;
+    q.hk = gt ? (pgt ? pk : tb) : q.hk;
+    q.hv = gt ? (pgt ? pv : (uint32_t)idx) : q.hv;
+    q.nh++;
+    q.h0 = tb < q.h0 ? tb : q.h0;
+}
+// pop the smallest (T, then oldest); -1 when empty (uniform)
+__device__ __attribute__((always_inline)) inline int wq_pop(WQ &q)
+{
+    const bool cold = q.head < q.tail;
+    if (!cold && q.nh == 0) return -1;
+    const uint32_t cT = cold ? (uint32_t)__builtin_amdgcn_readfirstlane((int)q.preT) : 0xFFFFFFFFu;
+    if (cold && cT <= q.h0) {
+        int idx = __builtin_amdgcn_readfirstlane((int)q.preI);
+        q.head++;
+        wq_prefetch(q);
+        return idx;
+    }
+    int idx = __builtin_amdgcn_readlane((int)q.hv, 0);
+    q.hk = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)q.hk, 0x130, 0xf, 0xf, false);              // wave_shl1: lane l <- l+1
+    q.hv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q.hv, 0x130, 0xf, 0xf, false);
+    q.nh--;
+    q.h0 = (uint32_t)__builtin_amdgcn_readlane((int)q.hk, 0);
+    return idx;
+}
+
+// FMM quadrant solve (inpaint.cpp FastMarching_solve): a11 / a22 = T of the vertical / horizontal neighbour,
+// k1 / k2 = that neighbour is not INSIDE
+__device__ inline float wn_solve(double a11, double a22, bool k1, bool k2)
+{
+    double m12 = a11 < a22 ? a11 : a22;
+    double sol;
+    if (k1) {
+        if (k2) {
+            if (fabs(a11 - a22) >= 1.0) sol = 1 + m12;
+            else sol = (a11 + a22 + sqrt((double)(2 - (a11 - a22) * (a11 - a22)))) * 0.5;
+        } else sol = 1 + a11;
+    } else if (k2) sol = 1 + a22;
+    else sol = 1 + m12;
+    return (float)sol;
+}
+
+// next seed (initial band pixel) in raster order, -1 when exhausted; (base, pend) is the scan state
+__device__ inline int wn_next_seed(const uint8_t *f, int cells, int &base, unsigned long long &pend, int lane)
+{
+    while (!pend && base < cells) {
+        int li = base + lane;
+        pend = __ballot(li < cells && (f[li] & W_SEED));
+        if (!pend) base += 64;
+    }
+    if (!pend) return -1;
+    int l = __ffsll((long long)pend) - 1;
+    pend &= pend - 1;
+    int p = base + l;
+    if (!pend) base += 64;
+    return p;
+}
+
+// The march on one window.  CL = false: the window holds every hole pixel of the frame (lab / rootp unused).
+// CL = true: only the hole pixels of the cluster `rootp` (label plane `lab`) are INSIDE; hole pixels of other
+// clusters that happen to lie in the window are treated as known pixels -- they are farther than range + 1 from
+// every pixel this march reads, and they are restored by their own march.  Returns false when the queue overflowed
+
+// ---- the two per-pop bodies of the march, shared by the single-wave and the multi-wave kernels -------------------------
+struct TeleaWin {
+    float *t, *im;          // LDS planes of the window: T field, image
+    uint8_t *f;             // flag bytes
+    int ww;                 // row pitch of the window
+};
+struct TeleaOutsideConsts { int dn, d1, d2; };       // lanes 0..15 = 4 neighbours x 4 quadrants
+__device__ inline TeleaOutsideConsts telea_outside_consts(int lane, int ww)
+{
+    const int nb = (lane >> 2) & 3, qd = lane & 3;
+    TeleaOutsideConsts c;
+    c.dn = nb == 0 ? -ww : nb == 1 ? -1 : nb == 2 ? ww : 1;
+    c.d1 = (qd & 1) ? ww : -ww;
+    c.d2 = (qd & 2) ? 1 : -1;
+    return c;
+}
+// this lane's neighbour offsets of the first two 64-neighbour chunks of the (2*range+1)^2 estimator window
+struct TeleaMarchConsts {
+    int off[2], d4, range, nn, side, r2;
+    float rx[2], ry[2], dstw[2];
+    bool on[2];
+};
+__device__ inline TeleaMarchConsts telea_march_consts(int lane, int ww, int range)
+{
+    TeleaMarchConsts c;
+    c.range = range; c.r2 = range * range; c.side = 2 * range + 1; c.nn = c.side * c.side;
+#pragma unroll
+    for (int c2 = 0; c2 < 2; c2++) {
+        int nidx = c2 * 64 + lane;
+        int dk = nidx / c.side - range, dl = nidx % c.side - range;
+        c.off[c2] = dk * ww + dl;
+        c.on[c2] = nidx < c.nn && (dl * dl + dk * dk <= c.r2);
+        float ry = (float)(-dk), rx = (float)(-dl);
+        c.rx[c2] = rx; c.ry[c2] = ry;
+        float len2 = __fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry));
+        c.dstw[c2] = len2 > 0.f ? (float)(1. / (double)__fmul_rn(len2, __fsqrt_rn(len2))) : 0.f;
+    }
+    c.d4 = (lane & 3) == 0 ? -ww : (lane & 3) == 1 ? -1 : (lane & 3) == 2 ? ww : 1;    // up, left, down, right
+    return c;
+}
+
+// Outside T field (icvCalcFMM with `negate`): pop p (a seed of the initial band or a queue entry), give every ring
+// neighbour its T and push it.  States are those of OpenCV's `out` mask: ring = INSIDE, hole and everything else KNOWN.
+template <class Push>
+__device__ __attribute__((always_inline)) inline void telea_pop_outside(const TeleaWin &win, const TeleaOutsideConsts &oc, int p, bool seed, int lane,
+                                                                        Push push)
+{
+    float *t = win.t;
+    uint8_t *f = win.f;
+    const int dn = oc.dn, d1 = oc.d1, d2 = oc.d2;
+    if (lane == 0) f[p] = (uint8_t)(seed ? (W_SEED | W_CHANGE) : W_CHANGE);   // ring pixels carry no other bit that matters
+    const int pn = p + dn;
+    bool ok = lane < 16 && (f[pn] & W_ST) == W_INSIDE;
+    if (!__ballot(ok)) return;
+    float dist = 0.f;
+    if (ok) {
+        const int p1 = pn + d1, p2 = pn + d2;
+        float a11 = t[p1], a22 = t[p2];
+        uint8_t f1 = f[p1], f2 = f[p2];
+        dist = wn_solve(a11, a22, (f1 & W_ST) != W_INSIDE, (f2 & W_ST) != W_INSIDE);
+    }
+    float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dist), 0xB1, 0xf, 0xf, false)); dist = o < dist ? o : dist;
+    o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dist), 0x4E, 0xf, 0xf, false)); dist = o < dist ? o : dist;
+    for (int k = 0; k < 4; k++) {
+        bool okk = __builtin_amdgcn_readlane((int)ok, k * 4) != 0;
+        if (!okk) continue;
+        float dk = wn_lane_f(dist, k * 4);
+        int pk = __builtin_amdgcn_readlane(pn, k * 4);
+        if (lane == 0) { t[pk] = dk; f[pk] = W_BAND; }
+        push(dk, pk);
+    }
+}
+
+// Telea march (icvTeleaInpaintFMM): pop p, fill every 4-neighbour that is still INSIDE and push it.  Returns the number of
+// pixels filled.
+template <class Push>
+__device__ __attribute__((always_inline)) inline int telea_pop_march(const TeleaWin &win, const TeleaMarchConsts &mc, int p, bool from_queue, int lane,
+                                                                     Push push)
+{
+    float *t = win.t, *im = win.im;
+    uint8_t *f = win.f;
+    const int ww = win.ww, d4 = mc.d4, range = mc.range, nn = mc.nn, side = mc.side, r2 = mc.r2;
+    const int *h_off = mc.off;
+    const float *h_rx = mc.rx, *h_ry = mc.ry, *h_dstw = mc.dstw;
+    const bool *h_on = mc.on;
+    int nfill = 0;
+    if (from_queue && lane == 0) f[p] = (uint8_t)(W_HOLE | W_KNOWN);
+    // the four 4-neighbours, one per lane: still INSIDE?  (a neighbour's fill never changes another's flag)
+    unsigned todo = (unsigned)(__ballot(lane < 4 && (f[p + d4] & W_ST) == W_INSIDE) & 0xf);
+    while (todo) {
+        const int qn = __ffs((int)todo) - 1;
+        todo &= todo - 1;
+        const int pi = p + (qn == 0 ? -ww : qn == 1 ? -1 : qn == 2 ? ww : 1);
+        nfill++;
+        // (flag, T) of pi's up / left / down / right neighbours on lanes 0..3, shared by all lanes
+        const uint8_t f4 = f[pi + d4];
+        const float t4 = t[pi + d4];
+        const bool k4 = (f4 & W_ST) != W_INSIDE;
+        const float tu = wn_lane_f(t4, 0), tl = wn_lane_f(t4, 1), td = wn_lane_f(t4, 2), tr = wn_lane_f(t4, 3);
+        const unsigned kk = (unsigned)__ballot(k4) & 0xf;
+        const bool ku = kk & 1, kl = kk & 2, kd = kk & 4, kr = kk & 8;
+        float dist;
+        {
+            const int qd = lane & 3;      // quadrants (i-1,j-1) (i+1,j-1) (i-1,j+1) (i+1,j+1)
+            float s = wn_solve((qd & 1) ? td : tu, (qd & 2) ? tr : tl, (qd & 1) ? kd : ku, (qd & 2) ? kr : kl);
+            float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0xB1, 0xf, 0xf, false)); s = o < s ? o : s;
+            o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x4E, 0xf, 0xf, false)); s = o < s ? o : s;
+            dist = wn_lane_f(s, 0);
+        }
+        if (lane == 0) t[pi] = dist;
+        __builtin_amdgcn_wave_barrier();
+        const float tc = dist;
+        float gtx, gty;
+        if (kr) gtx = kl ? __fmul_rn(__fsub_rn(tr, tl), 0.5f) : __fsub_rn(tr, tc);
+        else gtx = kl ? __fsub_rn(tc, tl) : 0.f;
+        if (kd) gty = ku ? __fmul_rn(__fsub_rn(td, tu), 0.5f) : __fsub_rn(td, tc);
+        else gty = ku ? __fsub_rn(tc, tu) : 0.f;
+        float aIa = 0.f, aJx = 0.f, aJy = 0.f, aS = 0.f;
+        for (int n0 = 0; n0 < nn; n0 += 64) {
+            int off;
+            float dstw, rx, ry;
+            bool on;
+            if (n0 < 128) { int c2 = n0 >> 6; off = h_off[c2]; dstw = h_dstw[c2]; on = h_on[c2]; rx = h_rx[c2]; ry = h_ry[c2]; }
+            else {
+                int nidx = n0 + lane;
+                int dk = nidx / side - range, dl = nidx % side - range;
+                off = dk * ww + dl;
+                on = nidx < nn && (dl * dl + dk * dk <= r2);
+                ry = (float)(-dk); rx = (float)(-dl);
+                float len2 = __fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry));
+                dstw = len2 > 0.f ? (float)(1. / (double)__fmul_rn(len2, __fsqrt_rn(len2))) : 0.f;
+            }
+            if (on) {
+                const int pk = pi + off;                      // inside the window: margin range+1
+                const uint8_t f0 = f[pk], fr = f[pk + 1], fl = f[pk - 1], fd = f[pk + ww], fu = f[pk - ww];
+                const float tk = t[pk];
+                float vC = im[pk], vA = im[pk + 1], vB = im[pk - 1], vE = im[pk + ww], vF = im[pk - ww];
+                if (!(f0 & W_BORDER) && (f0 & W_ST) != W_INSIDE) {
+                    float vD = vC, vG = vC;
+                    if ((fr | fl | fd | fu) & W_BORDER) {
+                        // OpenCV's index shifts at the first / last image row / column (km, kp, lm, lp)
+                        const int sk = (fu & W_BORDER) ? 1 : 0, sK = (fd & W_BORDER) ? 1 : 0;
+                        const int sl = (fl & W_BORDER) ? 1 : 0, sL = (fr & W_BORDER) ? 1 : 0;
+                        const int rowm = pk + sk * ww;
+                        vC = im[rowm + sl]; vA = im[rowm + 1 - sL]; vB = im[rowm + sl - 1]; vD = im[rowm - sL];
+                        vE = im[pk + (1 - sK) * ww + sl]; vF = im[rowm - ww + sl]; vG = im[pk - sK * ww + sl];
+                    }
+                    // 1 / (1 + |T - Tc|): OpenCV forms it in double and rounds to float; the float quotient differs
+                    // from that by at most one ulp of a weight, far inside the estimator's own rounding noise
+                    float lev = __fdiv_rn(1.0f, __fadd_rn(1.0f, fabsf(__fsub_rn(tk, tc))));
+                    float dir = __fadd_rn(__fmul_rn(rx, gtx), __fmul_rn(ry, gty));
+                    if (fabsf(dir) <= 0.01f) dir = 0.000001f;   // float(0.01) < 0.01: same set of floats as the double compare
+                    float wgt = fabsf(__fmul_rn(__fmul_rn(dstw, lev), dir));
+                    const bool nr = (fr & W_ST) != W_INSIDE, nl = (fl & W_ST) != W_INSIDE, nd = (fd & W_ST) != W_INSIDE, nu = (fu & W_ST) != W_INSIDE;
+                    float gix, giy;
+                    if (nr) gix = nl ? __fmul_rn(__fsub_rn(vA, vB), 2.0f) : __fsub_rn(vA, vC);
+                    else gix = nl ? __fsub_rn(vD, vB) : 0.f;
+                    if (nd) giy = nu ? __fmul_rn(__fsub_rn(vE, vF), 2.0f) : __fsub_rn(vE, vC);
+                    else giy = nu ? __fsub_rn(vG, vF) : 0.f;
+                    aIa = __fadd_rn(aIa, __fmul_rn(wgt, vC));
+                    aJx = __fsub_rn(aJx, __fmul_rn(wgt, __fmul_rn(gix, rx)));
+                    aJy = __fsub_rn(aJy, __fmul_rn(wgt, __fmul_rn(giy, ry)));
+                    aS = __fadd_rn(aS, wgt);
+                }
+            }
+        }
+        const float Ia = wn_dpp_sum(aIa), Jx = wn_dpp_sum(aJx), Jy = wn_dpp_sum(aJy), s = __fadd_rn(wn_dpp_sum(aS), 1.0e-20f);
+        // Ia/s + (Jx+Jy)/(sqrt(Jx^2+Jy^2) + 1e-20): the second term is a ratio in [-sqrt2, sqrt2]; OpenCV forms it in
+        // double, its float evaluation differs by < 2e-7 absolute before the final rounding to float
+        const float nrm = __fadd_rn(__fsqrt_rn(__fadd_rn(__fmul_rn(Jx, Jx), __fmul_rn(Jy, Jy))), 1.0e-20f);
+        const float val = __fadd_rn(__fdiv_rn(Ia, s), __fdiv_rn(__fadd_rn(Jx, Jy), nrm));
+        if (lane == 0) { im[pi] = val; f[pi] = (uint8_t)(W_HOLE | W_BAND); }
+        push(dist, pi);
+    }
+    return nfill;
+}
+
+}  // namespace vf
