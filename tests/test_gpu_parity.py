@@ -313,3 +313,4 @@ def test_non_square_odd_sizes(pkg, cal):
         s = out["scalars"][b].cpu().numpy()
         assert int(s[4]) == o["argmax_depth_index"]
         assert int(out["status"][b]) == 0
+

@@ -1,4 +1,4 @@
-// Shared pieces of the LDS-resident Telea march (k_inpaint_win.hip, k_inpaint_mw.hip): flag byte layout, DPP helpers, the
+// Shared pieces of the LDS-resident Telea march (k_inpaint_win.hip: frame-window and cluster kernels): flag byte layout, DPP helpers, the
 // two-run stable priority queue, the FMM quadrant solve and the raster seed scan.
 #pragma once
 #include "kernels.hpp"
@@ -49,6 +49,8 @@ __device__ __attribute__((always_inline)) inline void wq_prefetch(WQ &q)
     unsigned long long v = q.e[q.head & (q.cap - 1)];
     q.preT = (uint32_t)(v >> 32); q.preI = (uint32_t)v;
 }
+// PRE: keep a prefetched copy of the cold head for wq_pop (false: the caller reads the run itself)
+template <bool PRE = true>
 __device__ __attribute__((always_inline)) inline void wq_merge(WQ &q, int lane)
 {
     int n = q.tail - q.head;
@@ -95,15 +97,16 @@ __device__ __attribute__((always_inline)) inline void wq_merge(WQ &q, int lane)
         if (act) q.e[q.head + j + l2] = v;
         __builtin_amdgcn_wave_barrier();
     }
-    q.e[q.head + c + lane] = ((unsigned long long)q.hk << 32) | q.hv;
+    if (lane < q.nh) q.e[q.head + c + lane] = ((unsigned long long)q.hk << 32) | q.hv;      // lanes >= nh are empty (key 0xFFFFFFFF sorts last)
     __builtin_amdgcn_wave_barrier();
-    q.tail += 64;
+    q.tail += q.nh;
     q.nh = 0; q.hk = 0xFFFFFFFFu; q.h0 = 0xFFFFFFFFu;
-    wq_prefetch(q);
+    if (PRE) wq_prefetch(q);
 }
+template <bool PRE = true>
 __device__ __attribute__((always_inline)) inline void wq_push(WQ &q, float Tf, int idx, int lane)
 {
-    if (q.nh == 64) { wq_merge(q, lane); if (q.ovf) return; }
+    if (q.nh == 64) { wq_merge<PRE>(q, lane); if (q.ovf) return; }
     const uint32_t tb = __float_as_uint(Tf);
     const uint32_t pk = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q.hk, 0x138, 0xf, 0xf, false);    // wave_shr1: lane l <- l-1, lane 0 <- 0
     const uint32_t pv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q.hv, 0x138, 0xf, 0xf, false);
@@ -170,7 +173,7 @@ __device__ inline int wn_next_seed(const uint8_t *f, int cells, int &base, unsig
 // clusters that happen to lie in the window are treated as known pixels -- they are farther than range + 1 from
 // every pixel this march reads, and they are restored by their own march.  Returns false when the queue overflowed
 
-// ---- the two per-pop bodies of the march, shared by the single-wave and the multi-wave kernels -------------------------
+// ---- the two per-pop bodies of the march, shared by the frame-window and the cluster kernel -------------------------
 struct TeleaWin {
     float *t, *im;          // LDS planes of the window: T field, image
     uint8_t *f;             // flag bytes
