@@ -127,15 +127,10 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit(const float *__restric
     ctx.order = order; ctx.med = 0.f; ctx.mode = 0;
     for (int i = 0; i < 6; i++) ctx.coef[i] = 0.f;
 
-    // ---- number of fitted pixels (mask != 0 and finite z)
-    uint32_t n;
-    {
-        uint32_t cnt = 0;
-        sel_foreach(ctx, P, [&](uint32_t) { cnt++; });
-        __syncthreads();
-        n = block_sum<uint32_t>(cnt, sh.wsum);
-        __syncthreads();
-    }
+    // ---- number of fitted pixels (mask != 0 and finite z) and the range of z (coefficients are still zero: r = z)
+    uint32_t n, zkmin, zkmax;
+    block_minmax(ctx, P, sh, n, zkmin, zkmax);
+    const float zmin = key2f(zkmin), zmax = key2f(zkmax);
     const bool do_fit = (int)n >= min_count;
 
     float csig = 1.f;      // c * sigma of the previous iteration
@@ -210,9 +205,16 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit(const float *__restric
         for (int i = 0; i < 6; i++) ctx.coef[i] = s_coef[i];
         if (it == iters - 1) break;   // the weights of the last iteration are never used upstream
         // ---- sigma = 1.4826 * (median |r - median r| + 1e-6)
-        uint32_t nn, kmin, kmax;
+        // range of r = z - fit without a pass over the data: |xn|, |yn| <= 1, so |fit| <= sum |coef| (plus rounding slack); the
+        // histogram refinement only needs a range that CONTAINS the values
+        uint32_t nn = n, kmin, kmax;
         ctx.mode = 0;
-        block_minmax(ctx, P, sh, nn, kmin, kmax);
+        {
+            float fb = 0.f;
+            for (int i = 0; i < 6; i++) fb += fabsf(ctx.coef[i]);
+            fb = fb * 1.0001f + 1e-30f;
+            kmin = f2key(zmin - fb - 1e-6f * fabsf(zmin)); kmax = f2key(zmax + fb + 1e-6f * fabsf(zmax));
+        }
         float medr = block_median(ctx, P, sh, nn, kmin, kmax);
         __syncthreads();
         ctx.med = medr; ctx.mode = 1;
