@@ -9,7 +9,7 @@ normalise -> pruned-DFT demodulation -> reliable mask -> quality-guided unwrap -
 frontier/compose -> mm curve -> blob filter -> force tail) over one batch of synthetic 224x224x3 fp16 frames that
 are already resident in HBM, followed (N > 1) by the single RCCL all-gather of the outputs.
 Workload = BASELINE.json configs[2]: batch 256 per GPU (weak scaling: N GPUs process N*256 frames per step).
-Steps are issued round-robin to `--inflight` sessions (default 2), each with its own HIP stream and workspace, the way a
+Steps are issued round-robin to `--inflight` sessions (default 3), each with its own HIP stream and workspace, the way a
 serving loop would keep the GPU busy: the march kernels of the path run one wave per frame and leave most of a CU idle,
 which the other session's kernels fill.  `--inflight 1` gives strictly serial steps; `stage_ms` / `roofline` are always
 measured on one session alone.  Rank 0 prints ONE JSON line.
@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--constants", choices=["scaled", "shipped"], default="scaled")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=3,
                     help="sessions (each with its own HIP stream and workspace) that take the steps in turn, so consecutive steps overlap on the GPU; "
                          "1 = strictly serial steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")

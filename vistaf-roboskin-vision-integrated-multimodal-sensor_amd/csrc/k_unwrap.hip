@@ -242,7 +242,7 @@ void launch_unwrap(const float *wrapped, const float *quality, const uint8_t *ma
         ppar = (const int32_t *)g4;
         if (logged) {
             if (ev_mid) hipEventRecord(ev_mid, st);
-            launch_unwrap_replay(wrapped, g0, 2 * EN, parent, unwrapped, B, h, w, st);
+            launch_unwrap_replay(wrapped, g2, 2 * EN, parent, unwrapped, B, h, w, st);
             return;
         }
     } else if (cap > 0) {

@@ -4,7 +4,7 @@
 // k_unwrap_rank   (1024 threads / frame) replaces each masked pixel's float quality by its RANK in the
 //                 frame's total order (q ascending, ties: larger pixel index first, so that the larger
 //                 rank is exactly the reference heap's higher priority "-q, then smaller (y, x)").
-//                 Stable LSD radix sort, 8-bit digits (4 passes), wave-contiguous chunks, 4 tiles of loads in flight.  The rank codes are
+//                 Stable LSD radix sort, 11-bit digits (3 passes), wave-contiguous chunks, 4 tiles of loads in flight.  The rank codes are
 //                 written into a plane padded by one pixel of zeros on every side.
 // k_unwrap_flood_ranked (one wavefront / frame) holds the whole padded frame in LDS as one uint16 per
 //                 pixel (0 outside mask / border, 1 visited, 2 in frontier, >= 3 untouched with
@@ -54,11 +54,12 @@ __device__ inline uint32_t dpp_max8_u32(uint32_t v)
 // rank plane layout: [(h+2) x (w+2)] uint16 (frame stride padded to 8 elements), border = 0.
 // Sort structure: each of the 16 waves owns a contiguous range of the element array and walks it in
 // 64-element tiles (coalesced, L1-bypassing loads of data other waves wrote in the previous pass).
-// Counting uses a per-wave 256-bin LDS histogram; the stable scatter ranks a lane among the lanes of its
-// tile that share its digit with eight ballots (peer mask) + mbcnt.
+// Counting uses a per-wave 2048-bin LDS histogram (16 x 8 KB); the stable scatter ranks a lane among the lanes of its
+// tile that share its digit with eleven ballots (peer mask) + mbcnt.
 __device__ inline uint32_t ld_u32c(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline unsigned long long ld_u64c(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+constexpr int RK_BITS = 11, RK_NB = 1 << RK_BITS;   // 3 passes of 11 bits over the 32-bit keys
 constexpr int RK_U = 4;        // 64-element tiles in flight per wave (independent loads issued together)
 
 __global__ __launch_bounds__(RK_T) void k_unwrap_rank(const float *__restrict__ quality_all, const uint8_t *__restrict__ mask_all,
@@ -67,7 +68,8 @@ __global__ __launch_bounds__(RK_T) void k_unwrap_rank(const float *__restrict__ 
                                                       int h, int w)
 {
     // sort records: key << 32 | padded pixel index (one 8-byte scattered store per element and pass)
-    __shared__ uint32_t whist[16][256];    // [wave][digit] counts, then exclusive offsets
+    extern __shared__ uint32_t rk_lds[];
+    uint32_t (*whist)[RK_NB] = (uint32_t (*)[RK_NB])rk_lds;    // [16 waves][RK_NB digits] counts, then exclusive offsets (128 KB)
     __shared__ uint32_t wcount[16];
     const size_t b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(RK_T) void k_unwrap_rank(const float *__restrict__ 
     const float *q = quality_all + b * (size_t)P;
     const uint8_t *m = mask_all + b * (size_t)P;
     unsigned long long *rA = A_all + b * gstride, *rB = B_all + b * gstride;
-    uint32_t *inv = (uint32_t *)rB;             // reuses this frame's rB once the last pass has left the records in rA
+    uint32_t *inv = (uint32_t *)rA;             // three passes leave the records in rB: rA is free for the sorted pixel indices
     uint16_t *rk = rank_all + b * (size_t)((EN + 7) & ~7);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
@@ -123,34 +125,38 @@ __global__ __launch_bounds__(RK_T) void k_unwrap_rank(const float *__restrict__ 
     __syncthreads();
     if (n == 0) return;
 
-    // 2. stable LSD radix sort, 4 passes of 8 bits; wave `wid` owns elements [e0, e1)
+    // 2. stable LSD radix sort, 3 passes of 11 bits; wave `wid` owns elements [e0, e1)
     const int Mw = ((((int)n + 15) / 16) + 63) & ~63;
     const int e0 = min((int)n, wid * Mw), e1 = min((int)n, e0 + Mw);
     unsigned long long *rs = rA, *rd = rB;
-    for (int pass = 0; pass < 4; pass++) {
-        const int shift = pass * 8;
-        for (int i = lane; i < 256; i += 64) whist[wid][i] = 0;
+    for (int pass = 0; pass < 3; pass++) {
+        const int shift = pass * RK_BITS;
+        for (int i = lane; i < RK_NB; i += 64) whist[wid][i] = 0;
         for (int eb = e0; eb < e1; eb += 64 * RK_U) {
             uint32_t kk[RK_U];
 #pragma unroll
             for (int u = 0; u < RK_U; u++) { int e = eb + u * 64 + lane; kk[u] = e < e1 ? ld_u32c((const uint32_t *)&rs[e] + 1) : 0u; }
 #pragma unroll
             for (int u = 0; u < RK_U; u++)
-                if (eb + u * 64 + lane < e1) atomicAdd(&whist[wid][(kk[u] >> shift) & 255u], 1u);
+                if (eb + u * 64 + lane < e1) atomicAdd(&whist[wid][(kk[u] >> shift) & (RK_NB - 1)], 1u);
         }
         __syncthreads();
-        // exclusive offsets in (digit-major, wave-minor) order: thread t owns digit t >> 2, waves 4 * (t & 3) .. + 3
+        // exclusive offsets in (digit-major, wave-minor) order: thread t owns digits 2t and 2t + 1 of all 16 waves
         {
-            const int dg = tid >> 2, w0 = (tid & 3) * 4;
-            uint32_t v0 = whist[w0][dg], v1 = whist[w0 + 1][dg], v2 = whist[w0 + 2][dg], v3 = whist[w0 + 3][dg];
-            uint32_t mine = v0 + v1 + v2 + v3;
+            uint32_t mine = 0;
+#pragma unroll
+            for (int k = 0; k < 32; k++) mine += whist[k & 15][2 * tid + (k >> 4)];
             uint32_t incl = wave_scan_add(mine);
             if (lane == 63) wcount[wid] = incl;
             __syncthreads();
-            uint32_t add = 0;
-            for (int i = 0; i < wid; i++) add += wcount[i];
-            uint32_t ex = add + incl - mine;
-            whist[w0][dg] = ex; whist[w0 + 1][dg] = ex + v0; whist[w0 + 2][dg] = ex + v0 + v1; whist[w0 + 3][dg] = ex + v0 + v1 + v2;
+            uint32_t run = incl - mine;
+            for (int i = 0; i < wid; i++) run += wcount[i];
+#pragma unroll
+            for (int k = 0; k < 32; k++) {
+                uint32_t v = whist[k & 15][2 * tid + (k >> 4)];
+                whist[k & 15][2 * tid + (k >> 4)] = run;
+                run += v;
+            }
         }
         __syncthreads();
         for (int eb = e0; eb < e1; eb += 64 * RK_U) {
@@ -163,10 +169,10 @@ __global__ __launch_bounds__(RK_T) void k_unwrap_rank(const float *__restrict__ 
 #pragma unroll
             for (int u = 0; u < RK_U; u++) {
                 const bool ok = eb + u * 64 + lane < e1;
-                const uint32_t dgt = (uint32_t)(rr[u] >> (32 + shift)) & 255u;
+                const uint32_t dgt = (uint32_t)(rr[u] >> (32 + shift)) & (RK_NB - 1);
                 unsigned long long peers = __ballot(ok);
 #pragma unroll
-                for (int bit = 0; bit < 8; bit++) {
+                for (int bit = 0; bit < RK_BITS; bit++) {
                     unsigned long long bm = __ballot(ok && ((dgt >> bit) & 1u));
                     peers &= ((dgt >> bit) & 1u) ? bm : ~bm;
                 }
@@ -312,7 +318,7 @@ bool unwrap_ranked_supported(int h, int w)
 }
 
 // g0..g3: uint32 planes of gstride elements per frame (sort ping-pong); ppar: int32 plane of gstride elements
-// returns true when the growth kernel also left its pop records in g0 (stride 2 * gstride per frame) for launch_unwrap_replay
+// returns true when the growth kernel also left its pop records in g2 (stride 2 * gstride per frame) for launch_unwrap_replay
 bool launch_unwrap_ranked(const float *quality, const uint8_t *mask, uint32_t *g0, uint32_t *g1, uint32_t *g2, uint32_t *g3,
                           int32_t *ppar, size_t gstride, uint16_t *rank16, int32_t *seed, int32_t *status, int B, int h, int w,
                           hipStream_t st, hipEvent_t ev_flood)
@@ -321,20 +327,23 @@ bool launch_unwrap_ranked(const float *quality, const uint8_t *mask, uint32_t *g
     int cap = ranked_cap(EN);
     // g0|g1 and g2|g3 are contiguous (k_unwrap.hip): two planes of 8-byte sort records; the sorted pixel indices go to g2
     (void)g1; (void)g3;
-    hipLaunchKernelGGL(k_unwrap_rank, dim3(B), dim3(RK_T), 0, st, quality, mask, (unsigned long long *)g0, (unsigned long long *)g2, gstride,
-                       rank16, seed, h, w);
+    static bool rk_attr = false;
+    if (!rk_attr) { (void)hipFuncSetAttribute((const void *)k_unwrap_rank, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * RK_NB * (int)sizeof(uint32_t)); rk_attr = true; }   // + 64 B static
+    hipLaunchKernelGGL(k_unwrap_rank, dim3(B), dim3(RK_T), (size_t)16 * RK_NB * sizeof(uint32_t), st, quality, mask, (unsigned long long *)g0,
+                       (unsigned long long *)g2, gstride, rank16, seed, h, w);
     if (ev_flood) hipEventRecord(ev_flood, st);
     // growth loop: "batch" (default: 8 pops per step, k_unwrap_batch.hip), "hot" (one pop per step, sorted register list + rank
     // bitmap) or "scan" (frontier array scan)
     static int use_hot = -1;
     if (use_hot < 0) { const char *e = getenv("VISTAF_FLOOD"); use_hot = (e && !strcmp(e, "scan")) ? 0 : (e && !strcmp(e, "hot")) ? 1 : 2; }
     if (use_hot == 2 && unwrap_batch_supported(h, w)) {
-        // the sort records in g0|g1 are dead once the ranks are out: the growth kernel logs its pops there
-        launch_unwrap_flood_batch(rank16, seed, g2, 2 * gstride, ppar, gstride, g0, 2 * gstride, B, h, w, st);
+        // sorted pixel indices: g0 (stride 2 * gstride); the sort records in g2|g3 are dead once the ranks are out: the growth
+        // kernel logs its pops there
+        launch_unwrap_flood_batch(rank16, seed, g0, 2 * gstride, ppar, gstride, g2, 2 * gstride, B, h, w, st);
         return true;
     }
     if (use_hot && unwrap_hot_supported(h, w)) {
-        launch_unwrap_flood_hot(rank16, seed, g2, 2 * gstride, ppar, gstride, status, B, h, w, st);
+        launch_unwrap_flood_hot(rank16, seed, g0, 2 * gstride, ppar, gstride, status, B, h, w, st);
         return false;
     }
     static bool attr_set = false;
