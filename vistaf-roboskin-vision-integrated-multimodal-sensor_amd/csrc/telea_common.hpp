@@ -140,15 +140,23 @@ __device__ __attribute__((always_inline)) inline int wq_pop(WQ &q)
 // k1 / k2 = that neighbour is not INSIDE
 __device__ inline float wn_solve(double a11, double a22, bool k1, bool k2)
 {
-    double m12 = a11 < a22 ? a11 : a22;
-    double sol;
-    if (k1) {
-        if (k2) {
-            if (fabs(a11 - a22) >= 1.0) sol = 1 + m12;
-            else sol = (a11 + a22 + sqrt((double)(2 - (a11 - a22) * (a11 - a22)))) * 0.5;
-        } else sol = 1 + a11;
-    } else if (k2) sol = 1 + a22;
-    else sol = 1 + m12;
+    // Branch-free: on a lone wave every divergent branch costs more than the arithmetic it skips.  sqrt(2 - d^2) is only used for
+    // |d| < 1, i.e. an argument in (1, 2]: v_rsq_f64 and the two correction steps of the compiler's own f64 sqrt expansion, without
+    // its denormal scaling -- bit-identical to sqrt() on that range.
+    const double d = a11 - a22, m12 = a11 < a22 ? a11 : a22;
+    const bool wide = fabs(d) >= 1.0;
+    const double x = wide ? 2.0 : 2.0 - d * d;
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, hh = 0.5 * y;
+    const double r = fma(-hh, g, 0.5);
+    g = fma(g, r, g);
+    hh = fma(hh, r, hh);
+    double e = fma(-g, g, x);
+    g = fma(e, hh, g);
+    e = fma(-g, g, x);
+    g = fma(e, hh, g);
+    const double both = wide ? 1.0 + m12 : (a11 + a22 + g) * 0.5;
+    const double sol = k1 ? (k2 ? both : 1.0 + a11) : (k2 ? 1.0 + a22 : 1.0 + m12);
     return (float)sol;
 }
 
