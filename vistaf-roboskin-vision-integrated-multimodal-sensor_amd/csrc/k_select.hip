@@ -10,13 +10,14 @@ struct PlaneGetter {
     const float *v; const uint8_t *m; float le; bool use_le, use_abs;
     __device__ bool operator()(int i, uint32_t &key) const
     {
-        if (!m[i]) return false;
+        // both loads unconditional, so that the SEL_U elements of a batch are all in flight together (select.hpp: sel_foreach)
+        const uint8_t mk = m[i];
         float x = v[i];
-        if (!finitef(x)) return false;
+        bool ok = mk != 0 && finitef(x);
         if (use_abs) x = fabsf(x);
-        if (use_le && !(x <= le)) return false;
+        if (use_le && !(x <= le)) ok = false;
         key = f2key(x);
-        return true;
+        return ok;
     }
 };
 
