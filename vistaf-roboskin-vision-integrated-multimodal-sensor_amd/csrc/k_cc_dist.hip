@@ -117,12 +117,23 @@ __device__ inline void cc16_unite(uint16_t *L, int a, int b)
     }
 }
 
+// MLDS: the mask plane is staged in LDS too (P bytes behind the forest), so every neighbour test is an LDS read
+template <bool MLDS>
 __global__ __launch_bounds__(1024) void k_cc_label_lds(const uint8_t *__restrict__ mask, int32_t *__restrict__ labels, int h, int w)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t L16[];
     size_t b = blockIdx.x;
     int P = h * w;
-    const uint8_t *m = mask + b * (size_t)P;
+    const uint8_t *mg = mask + b * (size_t)P;
+    uint8_t *ml = (uint8_t *)(L16 + ((P + 2 + 7) & ~7));
+    if (MLDS) {
+        for (int p = threadIdx.x * 4; p < P; p += blockDim.x * 4) {
+            if (p + 3 < P && ((((uintptr_t)mg) & 3) == 0)) *(uint32_t *)(ml + p) = *(const uint32_t *)(mg + p);
+            else for (int k = 0; k < 4 && p + k < P; k++) ml[p + k] = mg[p + k];
+        }
+        __syncthreads();
+    }
+    const uint8_t *m = MLDS ? (const uint8_t *)ml : mg;
     for (int p = threadIdx.x; p < P; p += blockDim.x) {
         // start each pixel at the left end of a short horizontal run segment (cuts find chains)
         uint16_t l = 0xffffu;
@@ -153,10 +164,17 @@ __global__ __launch_bounds__(1024) void k_cc_label_lds(const uint8_t *__restrict
 void launch_cc_label(const uint8_t *mask, int32_t *labels, int B, int h, int w, hipStream_t st)
 {
     int P = h * w;
-    if (P <= 65535 && (size_t)(P + 2) * 2 <= 150 * 1024) {
+    const size_t forest = (size_t)((P + 2 + 7) & ~7) * 2;
+    if (P <= 65535 && forest + (size_t)P + 16 <= 160 * 1024) {
         static bool attr_set = false;
-        if (!attr_set) { hipFuncSetAttribute((const void *)k_cc_label_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-        hipLaunchKernelGGL(k_cc_label_lds, dim3(B), dim3(1024), (size_t)(P + 2) * 2, st, mask, labels, h, w);
+        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_cc_label_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        hipLaunchKernelGGL(k_cc_label_lds<true>, dim3(B), dim3(1024), forest + (size_t)P + 16, st, mask, labels, h, w);
+        return;
+    }
+    if (P <= 65535 && forest <= 150 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_cc_label_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        hipLaunchKernelGGL(k_cc_label_lds<false>, dim3(B), dim3(1024), forest, st, mask, labels, h, w);
         return;
     }
     hipLaunchKernelGGL(k_cc_label, dim3(B), dim3(1024), 0, st, mask, labels, h, w);
@@ -172,34 +190,65 @@ __global__ __launch_bounds__(1024) void k_cc_largest(const int32_t *__restrict__
     const int32_t *L = labels + b * (size_t)P;
     int32_t *A = area + b * (size_t)P;
     int lane = threadIdx.x & 63;
-    for (int p = threadIdx.x; p < P; p += blockDim.x) A[p] = 0;
+    constexpr int U = 4;                    // independent loads in flight per thread (the loops are bound by memory round trips)
+    const int T = blockDim.x;
+    for (int p = threadIdx.x; p < P; p += T) A[p] = 0;
     __threadfence();
     __syncthreads();
-    int Pr = ((P + 1023) / 1024) * 1024;
-    for (int p = threadIdx.x; p < Pr; p += blockDim.x) {
-        int root = p < P ? L[p] : -1;
-        unsigned long long active = __ballot(root >= 0);
-        while (active) {
-            int leader = __ffsll((long long)active) - 1;
-            int r0 = __shfl(root, leader, 64);
-            unsigned long long same = __ballot(root == r0);
-            if (lane == leader) atomicAdd(&A[r0], (int)__popcll(same));
-            active &= ~same;
+    int Pr = ((P + U * 1024 - 1) / (U * 1024)) * (U * 1024);
+    // run-length accumulation per wave: consecutive tiles mostly belong to the same (large) component, and an atomic per tile on one
+    // address serialises the whole frame in L2
+    int run_root = -1, run_cnt = 0;
+    for (int p0 = threadIdx.x; p0 < Pr; p0 += U * T) {
+        int root[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { int p = p0 + u * T; root[u] = p < P ? L[p] : -1; }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            unsigned long long active = __ballot(root[u] >= 0);
+            while (active) {
+                int leader = __ffsll((long long)active) - 1;
+                int r0 = __builtin_amdgcn_readlane(root[u], leader);
+                unsigned long long same = __ballot(root[u] == r0);
+                if (r0 == run_root) run_cnt += (int)__popcll(same);
+                else {
+                    if (run_root >= 0 && lane == 0) atomicAdd(&A[run_root], run_cnt);
+                    run_root = r0; run_cnt = (int)__popcll(same);
+                }
+                active &= ~same;
+            }
         }
     }
+    if (run_root >= 0 && lane == 0) atomicAdd(&A[run_root], run_cnt);
     __threadfence();
     __syncthreads();
     unsigned long long best = 0;
-    for (int p = threadIdx.x; p < P; p += blockDim.x) {
-        if (L[p] != p) continue;
-        int a = __hip_atomic_load(&A[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned long long key = ((unsigned long long)(unsigned int)a << 32) | (unsigned int)(0x7fffffff - p);
-        if (key > best) best = key;
+    for (int p0 = threadIdx.x; p0 < P; p0 += U * T) {
+        int lab[U], ar[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            int p = p0 + u * T;
+            lab[u] = p < P ? L[p] : -1;
+            ar[u] = p < P ? __hip_atomic_load(&A[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            int p = p0 + u * T;
+            if (lab[u] != p) continue;
+            unsigned long long key = ((unsigned long long)(unsigned int)ar[u] << 32) | (unsigned int)(0x7fffffff - p);
+            if (key > best) best = key;
+        }
     }
     best = block_max_u64(best, scratch);
     int broot = (best >> 32) ? (0x7fffffff - (int)(best & 0xffffffffu)) : -2;
-    for (int p = threadIdx.x; p < P; p += blockDim.x)
-        out[b * (size_t)P + p] = (uint8_t)(L[p] == broot && (!and_static || and_static[p]));
+    for (int p0 = threadIdx.x; p0 < P; p0 += U * T) {
+        int lab[U];
+        uint8_t as[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { int p = p0 + u * T; lab[u] = p < P ? L[p] : -1; as[u] = (p < P && and_static) ? and_static[p] : (uint8_t)1; }
+#pragma unroll
+        for (int u = 0; u < U; u++) { int p = p0 + u * T; if (p < P) out[b * (size_t)P + p] = (uint8_t)(lab[u] == broot && as[u]); }
+    }
 }
 
 void launch_cc_largest(const int32_t *labels, int32_t *area_scratch, unsigned long long *best, const uint8_t *and_static,
