@@ -314,3 +314,36 @@ def test_non_square_odd_sizes(pkg, cal):
         assert int(s[4]) == o["argmax_depth_index"]
         assert int(out["status"][b]) == 0
 
+
+
+@pytest.mark.parametrize("var,val", [("VISTAF_INPAINT", "seq"), ("VISTAF_INPAINT", "cluster"), ("VISTAF_FLOOD", "hot"), ("VISTAF_FLOOD", "scan")])
+def test_alternative_kernel_tiers_agree(pkg, cal, var, val):
+    """The fallback / opt-in kernels (whole-frame and cluster-parallel Telea, one-pop and scan floods) stay parity-green: same
+    frames through the default path and through the alternative, compared with each other and with the oracle."""
+    n, nb = 224, 6
+    cfg = pkg.FtpConfig.scaled(n)
+    ref, sensor = _sensor(pkg, cal, n, cfg, nb, config=3)
+    frames = pkg.synth.deformed_batch(n, 40, nb, config=3)
+    base = sensor.predict_batch(frames)
+    torch.cuda.synchronize()
+    hm0 = base["height_map_mm"].cpu().numpy().copy()
+    par0 = sensor.intermediate("parent", nb, torch.int32).cpu().numpy().copy()
+    os.environ[var] = val
+    try:
+        alt = sensor.predict_batch(frames)
+        torch.cuda.synchronize()
+        hm1 = alt["height_map_mm"].cpu().numpy().copy()
+        par1 = sensor.intermediate("parent", nb, torch.int32).cpu().numpy().copy()
+        st = alt["status"].cpu().numpy()
+    finally:
+        os.environ.pop(var, None)
+    assert (st == 0).all()
+    if var == "VISTAF_FLOOD":
+        assert np.array_equal(par0, par1)                                   # the growth tree is an integer result: identical
+        assert np.array_equal(hm0, hm1, equal_nan=True)
+    else:
+        # the Telea tiers reduce the estimator's float sums in different orders: within the path tolerance of each other
+        assert np.array_equal(np.isnan(hm0), np.isnan(hm1))
+        assert float(np.nanmax(np.abs(hm0 - hm1))) <= RTOL * float(np.nanmax(np.abs(hm0)))
+    rs = O.make_reference_state(ref, *pkg.synth.roi_circle(n), cfg)
+    _check_frame(alt, 0, O.process_frame(frames[0], rs, cfg, *cal), n)

@@ -174,8 +174,8 @@ void preprocess(vistaf_ftp_handle *hd, const void *frames, int format, int B, hi
             // VISTAF_INPAINT=cluster: first march every small independent cluster of hole pixels on its own window (pays off when
             // the hole mask is many separate blobs; the fringe crests of this path form a few large clusters per frame, so it is off
             // by default); =seq: whole-frame kernel only
-            static int mode = -1;
-            if (mode < 0) { const char *ev = getenv("VISTAF_INPAINT"); mode = (ev && !strcmp(ev, "seq")) ? 1 : (ev && !strcmp(ev, "cluster")) ? 0 : 2; }
+            const char *ev = getenv("VISTAF_INPAINT");          // read on every call: the parity tests switch between the tiers
+            const int mode = (ev && !strcmp(ev, "seq")) ? 1 : (ev && !strcmp(ev, "cluster")) ? 0 : 2;
             if (mode == 0 && inpaint_clusters_supported(range)) {
                 uint8_t *bad_big = nullptr;
                 launch_inpaint_clusters(hd->img, hd->bad1, range, hd->inpaint_cl_scratch, &bad_big, B, h, w, st);

@@ -14,13 +14,10 @@
 //        prefix ends with the candidate that produced it and the entry goes into HOT.
 // Everything else about a pop (parent = lexicographically smallest visited neighbour, fresh neighbours to the
 // frontier) touches only the candidate's own 3x3 block, so the committed pops are independent.
-#include <cstdio>
-#include <cstdlib>
 #include "kernels.hpp"
 
 namespace vf {
 
-__device__ unsigned long long g_bt_dbg[8];
 constexpr int BT_NW = 1024;    // 64-bit words of the cold bitmap (codes < 65536)
 constexpr int BT_K = 8;        // candidates per step
 
@@ -84,13 +81,10 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_batch(const uint16_t *__res
     int H = 1;                   // entries in HOT (wave-uniform)
     uint32_t tailv = (uint32_t)__builtin_amdgcn_readfirstlane((int)hot);   // hot entry of lane H-1, 0 when H == 0
     bool cold_any = false;       // the cold bitmap may be non-empty
-    unsigned long long d_it = 0, d_ref = 0, d_cutC = 0, d_cutH = 0, d_t0 = __builtin_amdgcn_s_memtime();
 
     for (;;) {
         // ---- refill: HOT holds fewer than K entries: append the top cold codes (already in descending order)
-        d_it++;
         if (H < BT_K && cold_any) {
-            d_ref++;
             unsigned long long l1 = lane < 16 ? L1[lane] : 0ull;
             unsigned long long nz = __ballot(l1 != 0ull);
             if (nz == 0ull) cold_any = false;
@@ -163,8 +157,8 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_batch(const uint16_t *__res
         const unsigned long long cmC = __ballot(conflict);
         const unsigned long long cmH = __ballot(e > clast);
         int m = mav;
-        if (cmC) { int g = (__ffsll((long long)cmC) - 1) >> 3; if (g < m) d_cutC++; m = g < m ? g : m; }
-        if (cmH) { int g = ((__ffsll((long long)cmH) - 1) >> 3) + 1; if (g < m) d_cutH++; m = g < m ? g : m; }
+        if (cmC) { int g = (__ffsll((long long)cmC) - 1) >> 3; m = g < m ? g : m; }
+        if (cmH) { int g = ((__ffsll((long long)cmH) - 1) >> 3) + 1; m = g < m ? g : m; }
 
         // ---- commit candidates 0..m-1
         const bool act = ci < m;
@@ -220,7 +214,6 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_batch(const uint16_t *__res
         if (coldb) cold_any = true;
     }
     if (lane == 0) order[ostride - 1] = (uint32_t)npop;
-    if (b == 0 && lane == 0) { g_bt_dbg[0] = d_it; g_bt_dbg[1] = d_ref; g_bt_dbg[2] = d_cutC; g_bt_dbg[3] = d_cutH; g_bt_dbg[4] = (unsigned long long)npop; g_bt_dbg[5] = __builtin_amdgcn_s_memtime() - d_t0; }
 }
 
 // k_unwrap_replay: integer wrap counts along the growth tree (shape_ftp.py:1060-1076) by replaying the pops in order.
@@ -306,12 +299,6 @@ void launch_unwrap_flood_batch(const uint16_t *rank16, const int32_t *seed, cons
     if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_unwrap_flood_batch, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
     const uint32_t magic = (uint32_t)(0x100000000ull / (unsigned)(w + 2)) + 1u;     // idx / (w + 2) == umulhi(idx, magic) for idx < 65536
     hipLaunchKernelGGL(k_unwrap_flood_batch, dim3(B), dim3(64), lds, st, rank16, seed, inv, inv_stride, ppar, gstride, order, ostride, h, w, magic);
-    if (getenv("VISTAF_FLOOD_DBG")) {
-        (void)hipStreamSynchronize(st);
-        unsigned long long g[8];
-        if (hipMemcpyFromSymbol(g, HIP_SYMBOL(g_bt_dbg), sizeof(g)) == hipSuccess)
-            printf("[flood batch dbg] frame 0: iterations %llu refills %llu cut-by-conflict %llu cut-by-order %llu pops %llu cycles %llu\n", g[0], g[1], g[2], g[3], g[4], g[5]);
-    }
 }
 
 // unwrapped = wrapped + 2*pi*k along the growth tree; NaN / parent -1 where the growth never arrived

@@ -1,5 +1,5 @@
 // k_unwrap_flood_hot: the growth loop of unwrap_quality_guided (shape_ftp.py:1043-1080) with an O(1)
-// frontier per step.  Same contract as k_unwrap_flood_ranked (k_unwrap_rank.hip): one wavefront per
+// frontier per step, one pop per step (VISTAF_FLOOD=hot; the default is the batched k_unwrap_flood_batch).  Same contract as k_unwrap_flood_ranked (k_unwrap_rank.hip): one wavefront per
 // frame, padded uint16 rank plane in LDS, parents written in padded index space.
 //
 // The frontier is split in two, with the invariant  every HOT entry > every COLD entry:
@@ -16,8 +16,6 @@
 // A single wave per CU is latency bound (measured on MI355X: 64 cycles per dependent ds_read, ~8.7 cycles per
 // dependent VALU op, ~25 cycles per VALU->SALU hop), so the common "downhill" step is written to have
 // one LDS round trip, two ballots and no cross-lane reduction.
-#include <cstdio>
-#include <cstdlib>
 #include "kernels.hpp"
 
 namespace vf {
@@ -35,8 +33,6 @@ __device__ inline uint32_t wave_shl1(uint32_t v) { return (uint32_t)__builtin_am
 // lane i <- lane i-1 (lane 0 <- 0)
 __device__ inline uint32_t wave_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
 
-__device__ unsigned long long g_flood_dbg[16];
-#define FSEC(acc) do { tt1 = __builtin_amdgcn_s_memtime(); acc += tt1 - tt0; tt0 = tt1; } while (0)
 constexpr int HOT_NW = 1024;   // 64-bit words of the code bitmap (codes < 65536)
 
 __global__ __launch_bounds__(64) void k_unwrap_flood_hot(const uint16_t *__restrict__ rank_all, const int32_t *__restrict__ seed_in,
@@ -81,8 +77,6 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_hot(const uint16_t *__restr
     uint32_t tailv = 0;          // hot entry of lane H-1 (uniform copy), 0 when H == 0
     if (lane == 0) { kp[cur] = 1; ppar[cur] = cur; }
     bool first = true;
-    unsigned long long ca = 0, cb = 0, cc = 0, cd = 0, ce = 0, tt0 = __builtin_amdgcn_s_memtime(), tt1, npx = 0, nref = 0, smax = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, rt0, rt1, nhot = 0, ncold = 0, nbeat = 0;
-    const unsigned long long tstart = tt0;
 
     for (;;) {
         uint32_t v = 0;
@@ -90,10 +84,7 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_hot(const uint16_t *__restr
         if (lane < 8) v = kp[np];
 
         // ---- HOT ran dry: pull the top <= 64 cold codes (descending) out of the bitmap
-        FSEC(ca);
         if (H == 0 && C > 0) {
-            nref++;
-            rt0 = __builtin_amdgcn_s_memtime();
             unsigned long long l1 = lane < 16 ? L1[lane] : 0ull;
             unsigned long long nz = __ballot(l1 != 0ull);
             int top1 = 63 - __clzll((long long)nz);
@@ -117,8 +108,6 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_hot(const uint16_t *__restr
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(maxtake, o, 64); maxtake = t > maxtake ? t : maxtake; }
             maxtake = __builtin_amdgcn_readfirstlane(maxtake);
-            smax += maxtake;
-            rt1 = __builtin_amdgcn_s_memtime(); r1 += rt1 - rt0; rt0 = rt1;
             for (int j = 0; j < maxtake; j++) {
                 if (j < take) {
                     int bit = 63 - __clzll((long long)rem);
@@ -126,24 +115,19 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_hot(const uint16_t *__restr
                     rem &= ~(1ull << bit);
                 }
             }
-            rt1 = __builtin_amdgcn_s_memtime(); r2 += rt1 - rt0; rt0 = rt1;
             if (take > 0) {
                 L0[wi] = rem;
                 if (rem == 0ull) atomicAnd(&L1[wi >> 6], ~(1ull << (wi & 63)));
             }
             uint32_t code = lane < total ? stage[lane] : 0u;
-            rt1 = __builtin_amdgcn_s_memtime(); r3 += rt1 - rt0; rt0 = rt1;
             uint32_t idx = lane < total ? inv[code - 3u] : 0u;
             hot = lane < total ? ((code << 16) | idx) : 0u;
             H = total;
             C -= total;
             head = (uint32_t)__builtin_amdgcn_readfirstlane((int)hot);
             tailv = (uint32_t)__builtin_amdgcn_readlane((int)hot, total - 1);
-            rt1 = __builtin_amdgcn_s_memtime(); r4 += rt1 - rt0; rt0 = rt1;
         }
 
-        FSEC(cb);
-        npx++;
         const bool fresh = v >= 3;
         const uint32_t e = fresh ? ((v << 16) | (uint32_t)np) : 0u;      // new frontier entries of lanes 0..7
         const unsigned long long visb = __ballot(v == 1);
@@ -167,8 +151,6 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_hot(const uint16_t *__restr
             if (H == 0) tailv = 0u;
         }
 
-        FSEC(cc);
-        if (beat) nbeat++;
         // ---- remaining new entries: HOT when they outrank the HOT tail (or the frontier is empty), else COLD
         unsigned long long hotb = (H > 0) ? __ballot(((app >> lane) & 1ull) && e > tailv)
                                           : ((C == 0) ? app : 0ull);
@@ -178,7 +160,6 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_hot(const uint16_t *__restr
             hotb &= hotb - 1ull;
             uint32_t el = (uint32_t)__builtin_amdgcn_readlane((int)e, l);
             if (H > 0 && !(el > tailv)) { coldb |= 1ull << l; continue; }   // the tail moved up meanwhile
-            nhot++;
             int pos = (int)__popcll(__ballot(hot > el));
             uint32_t displaced = (uint32_t)__builtin_amdgcn_readlane((int)hot, 63);
             uint32_t sh = wave_shr1(hot);
@@ -197,8 +178,6 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_hot(const uint16_t *__restr
                 tailv = (uint32_t)__builtin_amdgcn_readlane((int)hot, 63);
             }
         }
-        FSEC(cd);
-        ncold += __popcll(coldb);
         if ((coldb >> lane) & 1ull) {
             uint32_t c = e >> 16;
             atomicOr(&L0[c >> 6], 1ull << (c & 63u));
@@ -208,9 +187,7 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_hot(const uint16_t *__restr
         if ((app >> lane) & 1ull) kp[np] = 2;
         cur = next;
         if (lane == 0) kp[cur] = 1;
-        FSEC(ce);
     }
-    if (b == 0 && lane == 0) { unsigned long long *g = g_flood_dbg; g[0] = ca; g[1] = cb; g[2] = cc; g[3] = cd; g[4] = ce; g[5] = npx; g[6] = nref; g[7] = nhot; g[8] = ncold; g[9] = nbeat; g[10] = __builtin_amdgcn_s_memtime() - tstart; g[11] = smax; g[12] = r1; g[13] = r2; g[14] = r3; g[15] = r4; }
     (void)status;
 }
 
@@ -229,13 +206,6 @@ void launch_unwrap_flood_hot(const uint16_t *rank16, const int32_t *seed, const 
     static bool attr_set = false;
     if (!attr_set) { hipFuncSetAttribute((const void *)k_unwrap_flood_hot, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
     hipLaunchKernelGGL(k_unwrap_flood_hot, dim3(B), dim3(64), lds, st, rank16, seed, inv, inv_stride, ppar, gstride, status, h, w);
-    if (getenv("VISTAF_FLOOD_DBG")) {
-        hipStreamSynchronize(st);
-        unsigned long long g[16];
-        if (hipMemcpyFromSymbol(g, HIP_SYMBOL(g_flood_dbg), sizeof(g)) == hipSuccess)
-            printf("[flood dbg] frame 0: loop-top+read %llu | refill %llu | ballots+next %llu | hot inserts %llu | cold+writes %llu | total %llu | px %llu refills %llu hot %llu cold %llu beat %llu\n", g[0], g[1], g[2], g[3], g[4], g[10], g[5], g[6], g[7], g[8], g[9]);
-        printf("[flood dbg] refill: scan+reduce %llu | extract loop %llu (sum maxtake %llu) | writeback+stage %llu | inv load+finish %llu\n", g[12], g[13], g[11], g[14], g[15]);
-    }
 }
 
 }  // namespace vf

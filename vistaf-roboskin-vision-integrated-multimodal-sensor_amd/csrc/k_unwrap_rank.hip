@@ -334,8 +334,8 @@ bool launch_unwrap_ranked(const float *quality, const uint8_t *mask, uint32_t *g
     if (ev_flood) hipEventRecord(ev_flood, st);
     // growth loop: "batch" (default: 8 pops per step, k_unwrap_batch.hip), "hot" (one pop per step, sorted register list + rank
     // bitmap) or "scan" (frontier array scan)
-    static int use_hot = -1;
-    if (use_hot < 0) { const char *e = getenv("VISTAF_FLOOD"); use_hot = (e && !strcmp(e, "scan")) ? 0 : (e && !strcmp(e, "hot")) ? 1 : 2; }
+    const char *e = getenv("VISTAF_FLOOD");                     // read on every call: the parity tests switch between the kernels
+    const int use_hot = (e && !strcmp(e, "scan")) ? 0 : (e && !strcmp(e, "hot")) ? 1 : 2;
     if (use_hot == 2 && unwrap_batch_supported(h, w)) {
         // sorted pixel indices: g0 (stride 2 * gstride); the sort records in g2|g3 are dead once the ranks are out: the growth
         // kernel logs its pops there
