@@ -78,8 +78,15 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # VISTAF_BENCH_REHEARSE=1: rehearse the N > 1 control flow on a one-GPU box (every rank on cuda:0, gloo instead of RCCL)
+        rehearse = os.environ.get("VISTAF_BENCH_REHEARSE") == "1"
+        if rehearse:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         dist = None
     dev = torch.device("cuda", local_rank if world > 1 else 0)
@@ -107,10 +114,9 @@ def main():
     out = outs[0]
     torch.cuda.synchronize(dev)
     step_no = [0]
-    gathered_h = gathered_s = None
-    if world > 1:
-        gathered_h = torch.empty((world * B, n, n), dtype=torch.float32, device=dev)
-        gathered_s = torch.empty((world * B, out["scalars"].shape[1]), dtype=torch.float64, device=dev)
+    # N > 1: ONE RCCL all-gather per step -- maps, scalar records and status packed into one record per frame (parallel.PackedGather),
+    # issued on the session's own stream so that it overlaps the other sessions' kernels
+    gathers = [pkg.parallel.PackedGather(o, keys=("height_map_mm", "scalars", "status")) for o in outs] if world > 1 else None
 
     def step():
         k = step_no[0] % len(sensors)
@@ -121,10 +127,11 @@ def main():
             with torch.cuda.stream(streams[k]):
                 sensors[k].predict_batch(frames, outs[k])
         if world > 1:
-            if streams[k] is not None:
-                torch.cuda.current_stream(dev).wait_stream(streams[k])
-            dist.all_gather_into_tensor(gathered_h, outs[k]["height_map_mm"])
-            dist.all_gather_into_tensor(gathered_s, outs[k]["scalars"])
+            if streams[k] is None:
+                gathers[k].gather(outs[k])
+            else:
+                with torch.cuda.stream(streams[k]):
+                    gathers[k].gather(outs[k])
 
     for _ in range(args.warmup):
         step()
@@ -187,7 +194,7 @@ def main():
             "config": {
                 "workload": f"BASELINE configs[2]: batch {B}/GPU of {n}x{n}x3 fp16 fringe frames -> {n}x{n} f32 depth map + force scalars, "
                             f"full FTP path (inpaint, demod, unwrap, detrend, compose, force tail), constants {args.constants}-{n}; "
-                            f"inputs resident in HBM" + ("; one RCCL all-gather of maps+scalars per step" if world > 1 else ""),
+                            f"inputs resident in HBM" + ("; one RCCL all-gather of the packed outputs (maps + scalar records + status) per step" if world > 1 else ""),
                 "global_batch": world * B, "frame": [n, n, 3], "input_dtype": "fp16", "constants": args.constants,
                 "parallelism": f"dp{world}", "inflight_batches": len(sensors), "frames_with_nonzero_status": status_bad,
             },

@@ -131,6 +131,16 @@ def _gloo_worker(rank, world, port, pkg_name, q):
     local = {"height_map_mm": full_h[a:b].clone(), "scalars": full_s[a:b].clone()}
     got = par.all_gather_outputs(local)
     ok = torch.equal(got["height_map_mm"], full_h) and torch.equal(got["scalars"], full_s)
+    # the single-collective variant: maps (f32), scalars (f64), status (i32) and a byte mask packed into one record per frame
+    full_st = torch.arange(total, dtype=torch.int32)
+    full_m = (torch.arange(total * h * h) % 3 == 0).to(torch.uint8).reshape(total, h, h)
+    local2 = dict(local, status=full_st[a:b].clone(), output_reliable=full_m[a:b].clone())
+    pg = par.PackedGather(local2, keys=("height_map_mm", "scalars", "status", "output_reliable"))
+    for _ in range(2):                                                     # buffers are reused from step to step
+        g2 = pg.gather(local2)
+    ok = ok and torch.equal(g2["height_map_mm"], full_h) and torch.equal(g2["scalars"], full_s)
+    ok = ok and torch.equal(g2["status"], full_st) and torch.equal(g2["output_reliable"], full_m)
+    ok = ok and pg.frame_bytes % 8 == 0
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
