@@ -1,0 +1,97 @@
+"""N2: the GPU pre-path alignment against its CPU restatement (oracle/align_oracle.py) and, end to end,
+against the height map the reference stored for the FINAL_E pair.
+
+Inputs: the reference's own demo photographs `tests/golden/FINAL_reference.jpg` / `FINAL_E_deformed.jpg` (data files, decoded
+on the host with Pillow as cv2.imread would); expected: the aligned crop of `tests/golden/e2e_FINAL_E_deformed.npz`
+(produced by the oracle) and that fixture's stored reference output.
+
+Tolerances: the shift and the ECC warp are float computations (hipFFT vs NumPy FFT, GPU vs NumPy reductions):
+shift within 5e-3 px, warp translation within 2e-3 px and rotation within 2e-6 rad of the oracle's; the aligned uint8 crop may
+then differ from the oracle's by one grey level on a small fraction of the pixels.
+"""
+import os
+
+import numpy as np
+import pytest
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+pytestmark = pytest.mark.gpu
+
+
+def _imread_bgr(path):
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.ascontiguousarray(np.asarray(im.convert("RGB"))[..., ::-1])
+
+
+@pytest.fixture(scope="module")
+def photos():
+    return _imread_bgr(os.path.join(G, "FINAL_reference.jpg")), _imread_bgr(os.path.join(G, "FINAL_E_deformed.jpg"))
+
+
+@pytest.fixture(scope="module")
+def fixture():
+    return np.load(os.path.join(G, "e2e_FINAL_E_deformed.npz"))
+
+
+def test_geometry_and_reference_crop(pkg, photos, fixture):
+    al = pkg.FtpAligner(photos[0], max_batch=1)
+    assert al.circle_full == (2012, 1129, 591)
+    assert al.crop_box == (1421, 538, 2603, 1720) and al.crop_shape == (1182, 1182)
+    assert al.circle_crop == tuple(int(v) for v in fixture["circle"])
+    assert np.array_equal(al.reference_gray_crop.cpu().numpy(), fixture["ref_gray"])           # fixed-point BGR2GRAY: bit-exact
+
+
+def test_global_shift_only_matches_oracle(pkg, photos):
+    """phase correlation + fixed-point warpAffine of the ROI window, ECC off"""
+    from oracle import align_oracle as A
+    al = pkg.FtpAligner(photos[0], use_ecc=False, max_batch=1)
+    out = al.align(photos[1])
+    shift_o, resp_o = A.estimate_global_shift(A.bgr2gray_u8(photos[0]).astype(np.float32), A.bgr2gray_u8(photos[1]).astype(np.float32))
+    assert abs(out["shift"][0, 0] - shift_o[0]) <= 5e-3 and abs(out["shift"][0, 1] - shift_o[1]) <= 5e-3   # float32 FFTs (hipFFT vs pocketfft): measured 2.2e-3
+    assert abs(out["response"][0] - resp_o) <= 2e-2 * abs(resp_o)      # sum of a 5x5 window of a noise-dominated whitened correlation: 0.8 % measured
+    # same shift -> the warped, cropped, grey-converted window must be the oracle's bit for bit
+    M = np.array([[1, 0, np.float32(out["shift"][0, 0])], [0, 1, np.float32(out["shift"][0, 1])]], np.float32)
+    x1, y1, x2, y2 = al.crop_box
+    exp = A.bgr2gray_u8(A.warp_affine(photos[1], M, False, border="reflect")[y1:y2, x1:x2])
+    assert np.array_equal(out["aligned_gray"][0].cpu().numpy(), exp)
+    assert not out["ecc_failed"][0] and np.allclose(out["warp"][0], np.eye(2, 3))
+
+
+def test_ecc_alignment_matches_oracle_and_pins_the_path(pkg, photos, fixture):
+    al = pkg.FtpAligner(photos[0], max_batch=1)
+    out = al.align(photos[1])
+    assert not out["ecc_failed"][0]
+    wo = fixture["warp"].astype(np.float64)
+    wg = out["warp"][0]
+    assert abs(np.arcsin(wg[1, 0]) - np.arcsin(wo[1, 0])) <= 2e-6                 # rotation (rad); the oracle found 5.07e-3
+    assert abs(wg[0, 2] - wo[0, 2]) <= 2e-3 and abs(wg[1, 2] - wo[1, 2]) <= 2e-3   # translation (px); (6.53, -4.07)
+    assert 10 <= out["ecc_iters"][0] < 300 and abs(out["rho"][0] - 0.86777) <= 1e-4
+    got = out["aligned_gray"][0].cpu().numpy()
+    exp = fixture["def_gray_aligned"]
+    d = np.abs(got.astype(np.int16) - exp.astype(np.int16))
+    # two bilinear uint8 warps with 1/32-pixel coordinate quantisation: a 2e-3 px difference in the global shift flips some roundings
+    assert d.max() <= 3 and (d > 0).mean() <= 0.10 and (d > 1).mean() <= 2e-3, (int(d.max()), float((d > 0).mean()), float((d > 1).mean()))
+    # end to end on the GPU: photographs -> aligned crops -> FTP path, against the height map the reference stored
+    import torch
+    cal, neg = pkg.load_calibration(os.path.join(G, "calibration_phase_to_height.json"))
+    fm = pkg.load_force_calibration(os.path.join(G, "calibration_height_to_force.json"))["best_model"]
+    sensor = pkg.FtpSensor(al.reference_gray_crop, al.circle_crop, pkg.FtpConfig.as_shipped(), cal, neg, fm, max_batch=1)
+    o = sensor.predict_batch(out["aligned_gray"])
+    torch.cuda.synchronize()
+    hm = o["height_map_mm"][0].cpu().numpy()
+    g = fixture["height_crop_reference"]
+    assert np.array_equal(np.isfinite(hm), np.isfinite(g))
+    m = np.isfinite(g)
+    dd = np.abs(hm[m] - g[m])
+    assert float(dd.mean()) <= 3e-4 and float(dd.max()) <= 8e-3 and abs(float(np.nanmax(hm)) - float(np.nanmax(g))) <= 5e-4 * float(np.nanmax(g))
+
+
+def test_ecc_failure_returns_the_unaligned_crop(pkg, photos):
+    """a blank frame makes the ECC update fail (zero variance): upstream logs the cv2.error and keeps the unaligned crop"""
+    al = pkg.FtpAligner(photos[0], max_batch=2)
+    blank = np.full_like(photos[1], 90)
+    out = al.align(np.stack([photos[1], blank]))
+    assert not out["ecc_failed"][0] and out["ecc_failed"][1]
+    assert np.isnan(out["rho"][1]) and np.allclose(out["warp"][1], np.eye(2, 3))
+    assert (out["aligned_gray"][1].cpu().numpy() == 90).all()

@@ -21,6 +21,12 @@ def test_library_exports_every_declared_symbol(pkg):
         assert hasattr(lib, name), name
     assert sorted(pkg._lib.EXPORTS) == declared
     assert lib.vistaf_ftp_abi_version() == 1
+    hdr2 = open(os.path.join(ROOT, "include", "vistaf_align.h")).read()
+    declared2 = sorted(set(re.findall(r"\b(vistaf_align_\w+)\s*\(", hdr2)))
+    assert len(declared2) == 6
+    for name in declared2:
+        assert hasattr(lib, name), name
+    assert sorted(pkg._lib.ALIGN_EXPORTS) == declared2
 
 
 def test_default_config_is_the_reference_constants(pkg):

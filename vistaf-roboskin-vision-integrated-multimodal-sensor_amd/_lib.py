@@ -25,6 +25,10 @@ EXPORTS = [
     "vistaf_ftp_enable_stage_timing", "vistaf_ftp_get_stage_times", "vistaf_ftp_destroy",
     "vistaf_depth_map_to_volume", "vistaf_predict_force_from_volume",
 ]
+ALIGN_EXPORTS = [            # include/vistaf_align.h
+    "vistaf_align_default_config", "vistaf_align_create", "vistaf_align_destroy", "vistaf_align_geometry",
+    "vistaf_align_set_reference", "vistaf_align_batch",
+]
 
 
 class Curve(ctypes.Structure):
@@ -83,7 +87,7 @@ def load():
     lib.vistaf_ftp_destroy.restype = None
     lib.vistaf_depth_map_to_volume.argtypes = [vp, vp, ci, ci, ci, cd, cd, vp, vp]
     lib.vistaf_predict_force_from_volume.argtypes = [ctypes.POINTER(Curve), cd, ctypes.POINTER(cd)]
-    for fn in EXPORTS:
+    for fn in EXPORTS + ALIGN_EXPORTS:
         getattr(lib, fn)
     _lib = lib
     return lib

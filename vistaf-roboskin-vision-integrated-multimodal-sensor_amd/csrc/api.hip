@@ -18,6 +18,7 @@ namespace vf { void telea_debug_dump(); void telea_window_debug_dump(int B); }
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+namespace vf { int set_error(int code, const std::string &msg) { return fail(code, msg); } }   // for the other translation units of the ABI
 #define HIPCHK(x)                                                                                         \
     do {                                                                                                  \
         hipError_t e_ = (x);                                                                              \
