@@ -552,11 +552,19 @@ int vistaf_ftp_predict_batch(vistaf_ftp_handle *hd, const void *d_frames, int fo
     launch_select(qual, hd->roi, 0, nullptr, false, hd->req_amp, 1, hd->amp_thr, nullptr, B, P, st);
     launch_threshold_mask(qual, hd->roi, hd->amp_thr, hd->rel0, B, P, st);
     {
+        // MORPH_CLOSE with n iterations = n dilations then n erosions; the eroded-ROI mask applies to the result
         uint8_t *src = hd->rel0, *dst = hd->rel1;
-        for (int it = 0; it < c.valid_close_iters; it++) { launch_morph(src, dst, B, h, w, hd->se_close, true, nullptr, nullptr, st, hd->morph_pre); std::swap(src, dst); }
-        for (int it = 0; it < c.valid_close_iters; it++) {
-            launch_morph(src, dst, B, h, w, hd->se_close, false, it == c.valid_close_iters - 1 ? hd->roi : nullptr, nullptr, st, hd->morph_pre);
-            std::swap(src, dst);
+        if (c.valid_close_iters >= 1 && 2 * c.valid_close_iters <= 4) {
+            int ops[4];
+            for (int it = 0; it < c.valid_close_iters; it++) { ops[it] = 1; ops[c.valid_close_iters + it] = 0; }
+            launch_morph_seq(hd->rel0, hd->rel1, hd->rel2, B, h, w, hd->se_close, ops, 2 * c.valid_close_iters, hd->roi, nullptr, st, hd->morph_pre);
+            src = hd->rel1;
+        } else {
+            for (int it = 0; it < c.valid_close_iters; it++) { launch_morph(src, dst, B, h, w, hd->se_close, true, nullptr, nullptr, st, hd->morph_pre); std::swap(src, dst); }
+            for (int it = 0; it < c.valid_close_iters; it++) {
+                launch_morph(src, dst, B, h, w, hd->se_close, false, it == c.valid_close_iters - 1 ? hd->roi : nullptr, nullptr, st, hd->morph_pre);
+                std::swap(src, dst);
+            }
         }
         launch_cc_label(src, hd->labels, B, h, w, st);
         launch_cc_largest(hd->labels, hd->area, nullptr, hd->roi, hd->rel2, B, P, st);
@@ -581,15 +589,20 @@ int vistaf_ftp_predict_batch(vistaf_ftp_handle *hd, const void *d_frames, int fo
     launch_contact_mask(hd->resid0, hd->reliable, hd->thr3, hd->rel_count, hd->contact_count, (float)c.min_contact_frac, (float)c.max_contact_frac,
                         hd->contact, hd->thr_used, B, P, st);
     {
-        uint8_t *src = hd->contact, *dst = hd->contact_d;
         int iters = std::max(1, c.dilate_iters);
-        uint8_t *bufs[2] = {hd->contact_d, hd->cand};   // cand is free until the blob filter
-        for (int it = 0; it < iters; it++) {
-            dst = bufs[it & 1];
-            launch_morph(src, dst, B, h, w, hd->se_contact, true, nullptr, it == iters - 1 ? hd->reliable : nullptr, st, hd->morph_pre);
-            src = dst;
+        if (iters <= 4) {
+            int ops[4] = {1, 1, 1, 1};
+            launch_morph_seq(hd->contact, hd->contact_d, hd->cand, B, h, w, hd->se_contact, ops, iters, nullptr, hd->reliable, st, hd->morph_pre);   // cand is free until the blob filter
+        } else {
+            uint8_t *src = hd->contact, *dst = hd->contact_d;
+            uint8_t *bufs[2] = {hd->contact_d, hd->cand};
+            for (int it = 0; it < iters; it++) {
+                dst = bufs[it & 1];
+                launch_morph(src, dst, B, h, w, hd->se_contact, true, nullptr, it == iters - 1 ? hd->reliable : nullptr, st, hd->morph_pre);
+                src = dst;
+            }
+            if (src != hd->contact_d) HIPCHK(hipMemcpyAsync(hd->contact_d, src, (size_t)B * P, hipMemcpyDeviceToDevice, st));
         }
-        if (src != hd->contact_d) HIPCHK(hipMemcpyAsync(hd->contact_d, src, (size_t)B * P, hipMemcpyDeviceToDevice, st));
     }
     launch_background(hd->reliable, hd->contact_d, hd->rel_count, hd->bg_count, hd->background, B, P, st);
     launch_robust_polyfit(hd->phase1, hd->background, c.poly_order, c.irls_iters, (float)c.irls_c, 200, hd->coef, hd->detr, B, h, w, st);

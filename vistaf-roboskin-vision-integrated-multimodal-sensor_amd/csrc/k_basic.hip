@@ -171,8 +171,14 @@ __global__ void k_morph_prefix(const uint16_t *__restrict__ inc, uint8_t *__rest
 // 15x15 element costs a few hundred 64-bit ops per output word -- and unpacks.  Erosion is the dual: complement inside
 // the image, dilate, complement (out-of-image pixels never erode: cv::morphologyDefaultBorderValue).
 constexpr int MB_T = 256;
-__global__ __launch_bounds__(MB_T) void k_morph_bits(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int h, int w, RowSpanSE se,
-                                                     int dilate, const uint8_t *__restrict__ and_static, const uint8_t *__restrict__ and_frame)
+constexpr int MB_MAXOPS = 4;
+struct MorphSeq {               // up to MB_MAXOPS operations applied back to back on the packed plane (close = dilate, erode; n-fold dilate)
+    int n;
+    int dilate[MB_MAXOPS];
+    RowSpanSE se[MB_MAXOPS];
+};
+__global__ __launch_bounds__(MB_T) void k_morph_bits(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int h, int w, MorphSeq seq,
+                                                     const uint8_t *__restrict__ and_static, const uint8_t *__restrict__ and_frame)
 {
     extern __shared__ unsigned long long mb_lds[];
     const int W64 = (w + 63) >> 6, nw = h * W64;
@@ -180,41 +186,65 @@ __global__ __launch_bounds__(MB_T) void k_morph_bits(const uint8_t *__restrict__
     const size_t b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint8_t *s = src + b * (size_t)h * w;
+    // pack: the byte loads of a row are independent and issued together
     for (int y = wid; y < h; y += MB_T / 64)
-        for (int j = 0; j < W64; j++) {
-            int x = j * 64 + lane;
-            bool on = x < w && ((s[(size_t)y * w + x] != 0) == (dilate != 0));      // erode: complement inside the image
-            unsigned long long word = __ballot(on);
-            if (lane == 0) A[y * W64 + j] = word;
+        for (int j0 = 0; j0 < W64; j0 += 4) {
+            uint8_t px[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int x = (j0 + u) * 64 + lane; px[u] = (j0 + u < W64 && x < w) ? s[(size_t)y * w + x] : (uint8_t)0; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const unsigned long long word = __ballot(px[u] != 0);
+                if (lane == 0 && j0 + u < W64) A[y * W64 + j0 + u] = word;
+            }
         }
     __syncthreads();
-    const int r = se.k / 2;
-    for (int t = tid; t < nw; t += MB_T) {
-        const int y = t / W64, j = t - y * W64;
-        unsigned long long acc = 0ull;
-        for (int i = 0; i < se.k; i++) {
-            const int yy = y + i - r, a = se.hi[i];
-            if (yy < 0 || yy >= h || a < 0) continue;
-            const unsigned long long *row = A + yy * W64;
-            const unsigned long long wc = row[j], wl = j > 0 ? row[j - 1] : 0ull, wr = j < W64 - 1 ? row[j + 1] : 0ull;
-            unsigned long long m = wc;
-            for (int dd = 1; dd <= a; dd++) m |= (wc >> dd) | (wr << (64 - dd)) | (wc << dd) | (wl >> (64 - dd));
-            acc |= m;
+    const unsigned long long last_valid = (w & 63) ? ((1ull << (w & 63)) - 1ull) : ~0ull;     // columns of the last word that exist
+    for (int op = 0; op < seq.n; op++) {
+        const RowSpanSE &se = seq.se[op];
+        const bool dil = seq.dilate[op] != 0;
+        if (!dil) {                                             // erosion = complement inside the image, dilate, complement
+            for (int t = tid; t < nw; t += MB_T) { const int j = t % W64; A[t] = ~A[t] & (j == W64 - 1 ? last_valid : ~0ull); }
+            __syncthreads();
         }
-        O[t] = acc;
+        const int r = se.k / 2;
+        for (int t = tid; t < nw; t += MB_T) {
+            const int y = t / W64, j = t - y * W64;
+            unsigned long long acc = 0ull;
+            for (int i = 0; i < se.k; i++) {
+                const int yy = y + i - r, a = se.hi[i];
+                if (yy < 0 || yy >= h || a < 0) continue;
+                const unsigned long long *row = A + yy * W64;
+                const unsigned long long wc = row[j], wl = j > 0 ? row[j - 1] : 0ull, wr = j < W64 - 1 ? row[j + 1] : 0ull;
+                unsigned long long m = wc;
+                for (int dd = 1; dd <= a; dd++) m |= (wc >> dd) | (wr << (64 - dd)) | (wc << dd) | (wl >> (64 - dd));
+                acc |= m;
+            }
+            const unsigned long long valid = j == W64 - 1 ? last_valid : ~0ull;
+            O[t] = dil ? (acc & valid) : (~acc & valid);
+        }
+        __syncthreads();
+        unsigned long long *tmp = A; A = O; O = tmp;
     }
-    __syncthreads();
+    // unpack (A holds the result); the optional AND masks of a row are loaded together
     uint8_t *o = dst + b * (size_t)h * w;
     for (int y = wid; y < h; y += MB_T / 64)
-        for (int j = 0; j < W64; j++) {
-            int x = j * 64 + lane;
-            if (x >= w) continue;
-            size_t p = (size_t)y * w + x;
-            int v = (int)((O[y * W64 + j] >> lane) & 1ull);
-            if (!dilate) v ^= 1;
-            if (and_static && !and_static[p]) v = 0;
-            if (and_frame && !and_frame[b * (size_t)h * w + p]) v = 0;
-            o[p] = (uint8_t)v;
+        for (int j0 = 0; j0 < W64; j0 += 4) {
+            uint8_t ms[4], mf[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int x = (j0 + u) * 64 + lane;
+                const size_t p = (j0 + u < W64 && x < w) ? (size_t)y * w + x : 0;
+                ms[u] = and_static ? and_static[p] : (uint8_t)1;
+                mf[u] = and_frame ? and_frame[b * (size_t)h * w + p] : (uint8_t)1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int x = (j0 + u) * 64 + lane;
+                if (j0 + u >= W64 || x >= w) continue;
+                const int v = (int)((A[y * W64 + j0 + u] >> lane) & 1ull);
+                o[(size_t)y * w + x] = (uint8_t)(v && ms[u] && mf[u]);
+            }
         }
 }
 
@@ -231,8 +261,10 @@ void launch_morph(const uint8_t *src, uint8_t *dst, int B, int h, int w, const R
                   const uint8_t *and_static, const uint8_t *and_frame, hipStream_t st, uint16_t *prefix_scratch)
 {
     if (morph_bits_ok(se, h, w)) {
+        MorphSeq seq;
+        seq.n = 1; seq.dilate[0] = dilate ? 1 : 0; seq.se[0] = se;
         size_t lds = (size_t)h * ((w + 63) >> 6) * 16;
-        hipLaunchKernelGGL(k_morph_bits, dim3(B), dim3(MB_T), lds, st, src, dst, h, w, se, dilate ? 1 : 0, and_static, and_frame);
+        hipLaunchKernelGGL(k_morph_bits, dim3(B), dim3(MB_T), lds, st, src, dst, h, w, seq, and_static, and_frame);
         return;
     }
     dim3 grid((w + 255) / 256, h, B);
@@ -243,6 +275,29 @@ void launch_morph(const uint8_t *src, uint8_t *dst, int B, int h, int w, const R
         return;
     }
     hipLaunchKernelGGL(k_morph, grid, dim3(256), 0, st, src, dst, h, w, se, dilate ? 1 : 0, and_static, and_frame);
+}
+
+// n operations with the same element back to back (dilates[i] != 0: dilate, else erode); the AND masks apply to the final result.
+// One kernel (pack once, unpack once) when the bit-plane path applies; `tmp` is a scratch plane for the fallback chain.
+void launch_morph_seq(const uint8_t *src, uint8_t *dst, uint8_t *tmp, int B, int h, int w, const RowSpanSE &se, const int *dilates, int n,
+                      const uint8_t *and_static, const uint8_t *and_frame, hipStream_t st, uint16_t *prefix_scratch)
+{
+    if (n >= 1 && n <= MB_MAXOPS && morph_bits_ok(se, h, w)) {
+        MorphSeq seq;
+        seq.n = n;
+        for (int i = 0; i < n; i++) { seq.dilate[i] = dilates[i] ? 1 : 0; seq.se[i] = se; }
+        size_t lds = (size_t)h * ((w + 63) >> 6) * 16;
+        hipLaunchKernelGGL(k_morph_bits, dim3(B), dim3(MB_T), lds, st, src, dst, h, w, seq, and_static, and_frame);
+        return;
+    }
+    const uint8_t *cur = src;
+    for (int i = 0; i < n; i++) {
+        // alternate so that the last operation writes dst
+        uint8_t *out = ((n - 1 - i) & 1) ? tmp : dst;
+        const bool last = i == n - 1;
+        launch_morph(cur, out, B, h, w, se, dilates[i] != 0, last ? and_static : nullptr, last ? and_frame : nullptr, st, prefix_scratch);
+        cur = out;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

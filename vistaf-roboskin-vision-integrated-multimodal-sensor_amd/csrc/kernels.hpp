@@ -20,6 +20,8 @@ void launch_bad_flags(const float *img, const float *grad, const uint8_t *valid,
                       uint8_t *bad, int B, int P, hipStream_t st);
 void launch_morph(const uint8_t *src, uint8_t *dst, int B, int h, int w, const RowSpanSE &se, bool dilate,
                   const uint8_t *and_static, const uint8_t *and_frame, hipStream_t st, uint16_t *prefix_scratch = nullptr);
+void launch_morph_seq(const uint8_t *src, uint8_t *dst, uint8_t *tmp, int B, int h, int w, const RowSpanSE &se, const int *dilates, int n,
+                      const uint8_t *and_static, const uint8_t *and_frame, hipStream_t st, uint16_t *prefix_scratch = nullptr);
 void launch_gauss_rows(const float *src, float *dst, const float *kern, int ksize, int B, int h, int w, hipStream_t st);
 void launch_gauss_cols(const float *src, float *dst, const float *kern, int ksize, int B, int h, int w, hipStream_t st);
 void launch_illum_norm(const float *img, const float *blur, float *out, int B, int P, hipStream_t st);
