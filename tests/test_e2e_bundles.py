@@ -150,7 +150,7 @@ def test_loading_set_report_pins_the_oracle_on_75_more_photographs():
     rows = json.load(open(os.path.join(G, "e2e_loading_report.json")))
     assert len(rows) == 75 and not any(r["ecc_failed"] for r in rows)
     rel = lambda k: np.array([abs(r[k] - r["stored_" + k]) / abs(r["stored_" + k]) for r in rows])
-    assert (rel("mm_per_px") < 1e-9).all() and (rel("estimated_grating_period_px") < 1e-9).all()
+    assert (rel("mm_per_px") < 1e-5).all() and (rel("estimated_grating_period_px") < 1e-5).all()      # sub-bin carrier refinement: 8e-7
     d = rel("max_depth_mm")
     assert np.median(d) < 1e-4 and d.max() < 3e-2
     v = rel("volume_cm3")
