@@ -95,3 +95,21 @@ def test_ecc_failure_returns_the_unaligned_crop(pkg, photos):
     assert not out["ecc_failed"][0] and out["ecc_failed"][1]
     assert np.isnan(out["rho"][1]) and np.allclose(out["warp"][1], np.eye(2, 3))
     assert (out["aligned_gray"][1].cpu().numpy() == 90).all()
+
+
+def test_calibration_batch_job_driver(pkg, photos):
+    """N4 driver: photographs -> FtpAligner.align -> FtpSensor.predict_batch in batches -> per_image_results rows; every row
+    of the (repeated) FINAL_E photograph must equal the single-frame result, and batching must not change it."""
+    cal, neg = pkg.load_calibration(os.path.join(G, "calibration_phase_to_height.json"))
+    fm = pkg.load_force_calibration(os.path.join(G, "calibration_height_to_force.json"))["best_model"]
+    al = pkg.FtpAligner(photos[0], max_batch=2)
+    sensor = pkg.FtpSensor(al.reference_gray_crop, al.circle_crop, pkg.FtpConfig.as_shipped(), cal, neg, fm, max_batch=2)
+    items = [(f"sphere-{i + 1}.jpg", photos[1]) for i in range(3)]
+    rows = pkg.calibrate.per_image_rows(al, sensor, items, [0.5, 0.5, 1.0], batch=2, ftp_output_dir=lambda i, f, force: f"runs/{i + 1:03d}_{f[:-4]}_F{force}N")
+    assert [r["file"] for r in rows] == ["sphere-1.jpg", "sphere-2.jpg", "sphere-3.jpg"] and rows[2]["force_N"] == 1.0
+    assert rows[0]["ftp_output_dir"] == "runs/001_sphere-1_F0.5N"
+    for k in ("volume_cm3", "contact_area_mm2", "max_depth_mm", "mm_per_px", "estimated_grating_period_px"):
+        assert rows[0][k] == rows[1][k] == rows[2][k]                       # same photograph, any batch position: same bits
+    stored = {"volume_cm3": 0.11378655442935222, "contact_area_mm2": 304.914771865451, "max_depth_mm": 1.1214957237243652}   # FINAL_E result.json
+    for k, tol in (("volume_cm3", 2e-3), ("contact_area_mm2", 2e-3), ("max_depth_mm", 5e-4)):
+        assert abs(rows[0][k] - stored[k]) <= tol * stored[k], k

@@ -213,3 +213,29 @@ def test_result_writers_match_reference_schema(pkg, tmp_path):
     assert np.array_equal(np.load(paths["crop_npy"]), height, equal_nan=True)
     first = open(paths["crop_csv"]).readline().strip().split(",")
     assert len(first) == n and first[0] == "nan"
+
+
+def test_force_calibration_fit_reproduces_the_stored_model(pkg):
+    """N4 host logic: the six candidate curves fitted to the reference's own per-image table (75 rows, stored
+    `per_image_results.csv`) give the stored `calibration_model.json`: same best model, parameters, RMSE ranking."""
+    import csv
+    rows = list(csv.DictReader(open(os.path.join(G, "ref_per_image_results.csv"))))
+    assert len(rows) == 75 and [float(r["force_N"]) for r in rows[:6]] == [0.5] * 5 + [1.0]
+    stored = json.load(open(os.path.join(G, "calibration_height_to_force.json")))
+    model = pkg.calibrate.calibration_model(rows, stored["reference_path"], stored["deformed_dir"], stored["output_dir"])
+    assert list(model.keys()) == list(stored.keys())
+    for k in ("volume_definition", "grating_pitch_mm", "depth_eps_mm", "anchor_origin", "origin_weight"):
+        assert model[k] == stored[k]
+    b, sb = model["best_model"], stored["best_model"]
+    assert list(b.keys()) == list(sb.keys())
+    assert b["type"] == sb["type"] == "growth" and b["n_fit"] == 95 and b["n_samples"] == 75
+    for k in ("a", "b"):
+        assert abs(b["params"][k] - sb["params"][k]) <= 1e-5 * abs(sb["params"][k])          # scipy trust-region fit, same start values
+    assert abs(b["rmse"] - sb["rmse"]) <= 1e-8 * sb["rmse"] and abs(b["r2"] - sb["r2"]) <= 1e-8
+    assert b["equation"] == sb["equation"]
+    assert [c["type"] for c in model["candidates_summary"]] == [c["type"] for c in stored["candidates_summary"]]
+    for c, sc in zip(model["candidates_summary"], stored["candidates_summary"]):
+        assert abs(c["rmse"] - sc["rmse"]) <= 1e-6 * sc["rmse"], c["type"]
+    # prediction through the fitted model equals the C-ABI force curve
+    v = 0.11378655442935222
+    assert abs(float(pkg.calibrate.model_predict(b, v)) - pkg.predict_force_from_volume(b, v)) <= 1e-12
