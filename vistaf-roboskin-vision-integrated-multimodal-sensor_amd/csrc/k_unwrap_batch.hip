@@ -50,6 +50,7 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_batch(const uint16_t *__res
     unsigned long long *L0 = (unsigned long long *)(kp + EN8);           // [BT_NW] cold bitmap over codes
     unsigned long long *L1 = L0 + BT_NW;                                 // [16]    one bit per L0 word
     uint32_t *stage = (uint32_t *)(L1 + 16);                             // [64]    refill staging
+    uint16_t *icache = (uint16_t *)(stage + 64);                         // [256]   slice of inv just below the last refill (see refill)
     int32_t *ppar = ppar_all + b * gstride;
     const uint16_t *rk = rank_all + b * (size_t)EN8;
     const uint32_t *inv = inv_all + b * inv_stride;                         // inv[rank] = padded pixel index
@@ -81,6 +82,11 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_batch(const uint16_t *__res
     int H = 1;                   // entries in HOT (wave-uniform)
     uint32_t tailv = (uint32_t)__builtin_amdgcn_readfirstlane((int)hot);   // hot entry of lane H-1, 0 when H == 0
     bool cold_any = false;       // the cold bitmap may be non-empty
+    // inv prefetch: the top of the frontier is dense in code space, so the next refill mostly pulls codes just below the lowest
+    // code of this one.  Their pixel indices are fetched now (4 per lane, consumed at the next refill through an LDS slice), which
+    // takes the global-memory round trip out of the refill.
+    uint32_t pf[4] = {0u, 0u, 0u, 0u};
+    int pf_lo = 0, pf_n = 0;          // codes [pf_lo, pf_lo + pf_n) are in flight / cached (wave-uniform)
 
     for (;;) {
         // ---- refill: HOT holds fewer than K entries: append the top cold codes (already in descending order)
@@ -130,10 +136,22 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_batch(const uint16_t *__res
                 const int k = lane - H;
                 const bool mine = k >= 0 && k < total;
                 const uint32_t code = mine ? stage[k] : 3u;
-                const uint32_t idx = inv[code - 3u];
+                // the slice prefetched at the previous refill lands in LDS now
+#pragma unroll
+                for (int j = 0; j < 4; j++) icache[lane * 4 + j] = (uint16_t)pf[j];
+                __builtin_amdgcn_wave_barrier();
+                const bool hit = mine && (int)code >= pf_lo && (int)code < pf_lo + pf_n;
+                uint32_t idx = hit ? (uint32_t)icache[(int)code - pf_lo] : 0u;
+                if (mine && !hit) idx = inv[code - 3u];
                 hot = mine ? ((code << 16) | idx) : hot;
                 H += total;
                 tailv = (uint32_t)__builtin_amdgcn_readlane((int)hot, H - 1);
+                // prefetch the 256 codes below the lowest one pulled
+                const int clow = (int)(tailv >> 16);
+                pf_lo = clow - 256 < 3 ? 3 : clow - 256;
+                pf_n = clow - pf_lo;
+#pragma unroll
+                for (int j = 0; j < 4; j++) { const int cc = pf_lo + lane * 4 + j; pf[j] = cc < clow ? inv[cc - 3] : 0u; }
             }
         }
         if (H == 0) break;                                               // frontier exhausted
@@ -286,7 +304,7 @@ __global__ __launch_bounds__(64 * RP_NW) void k_unwrap_replay(const float *__res
 bool unwrap_batch_supported(int h, int w)
 {
     long EN = (long)(h + 2) * (w + 2);
-    long lds = (((EN + 7) & ~7L)) * 2 + (BT_NW + 16) * 8 + 256;
+    long lds = (((EN + 7) & ~7L)) * 2 + (BT_NW + 16) * 8 + 256 + 512;
     return EN <= 65533 && lds <= 160 * 1024;
 }
 
@@ -294,7 +312,7 @@ void launch_unwrap_flood_batch(const uint16_t *rank16, const int32_t *seed, cons
                                uint32_t *order, size_t ostride, int B, int h, int w, hipStream_t st)
 {
     long EN = (long)(h + 2) * (w + 2);
-    size_t lds = (size_t)(((EN + 7) & ~7L)) * 2 + (BT_NW + 16) * 8 + 256;
+    size_t lds = (size_t)(((EN + 7) & ~7L)) * 2 + (BT_NW + 16) * 8 + 256 + 512;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_unwrap_flood_batch, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
     const uint32_t magic = (uint32_t)(0x100000000ull / (unsigned)(w + 2)) + 1u;     // idx / (w + 2) == umulhi(idx, magic) for idx < 65536
