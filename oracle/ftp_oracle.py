@@ -724,7 +724,7 @@ def process_frame(def_gray_u8, ref_state, cfg, cal_model, cal_use_neg=True,
     # debug_ramp (:1357-1422) -- functional: subtracts an order-1 robust fit
     phase = unwrapped.copy()
     phase[~reliable] = np.nan
-    if phase[reliable].size >= 500:
+    if int(cfg.plane_order_for_removal) > 0 and phase[reliable].size >= 500:      # 0: no debug_ramp (Code/phase_to_height.py has none)
         _, fit1 = robust_polyfit2d(phase, reliable, order=int(cfg.plane_order_for_removal), iters=cfg.irls_iters, c=cfg.irls_c)
         phase = (phase - fit1).astype(np.float32)
     deramped = phase

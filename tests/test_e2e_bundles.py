@@ -157,3 +157,18 @@ def test_loading_set_report_pins_the_oracle_on_75_more_photographs():
     assert np.median(v) < 1e-3 and (v < 1e-2).sum() >= 70 and (v < 5e-2).sum() >= 74
     a = rel("contact_area_mm2")
     assert np.median(a) < 1e-3 and (a < 1e-2).sum() >= 70
+
+
+def test_arg_extremum_locations_under_phase_to_height_constants():
+    """tests/golden/e2e_phase_to_height_report.json: alignment oracle + path oracle with the constants of the reference's
+    offline calibrator (Code/phase_to_height.py: ROI erode 80, frontier band 300, no plane pre-removal) on its four calibration
+    photographs, against `Force/Phase_to_height/calibration_out/calibration_results.csv` -- the reference's stored
+    arg-extremum ("contact location") goldens.  Three locations are hit exactly, the fourth is one row off (a 4e-4 relative
+    difference in a flat minimum after a restated alignment)."""
+    rows = json.load(open(os.path.join(G, "e2e_phase_to_height_report.json")))
+    assert [r["stored_xy"] for r in rows] == [[703, 514], [607, 524], [729, 537], [722, 588]]
+    exact = sum(r["xy"] == r["stored_xy"] for r in rows)
+    assert exact >= 3
+    for r in rows:
+        assert abs(r["xy"][0] - r["stored_xy"][0]) <= 1 and abs(r["xy"][1] - r["stored_xy"][1]) <= 1
+        assert abs(r["min"] - r["stored_min"]) <= 1e-3 * abs(r["stored_min"])

@@ -347,3 +347,20 @@ def test_alternative_kernel_tiers_agree(pkg, cal, var, val):
         assert float(np.nanmax(np.abs(hm0 - hm1))) <= RTOL * float(np.nanmax(np.abs(hm0)))
     rs = O.make_reference_state(ref, *pkg.synth.roi_circle(n), cfg)
     _check_frame(alt, 0, O.process_frame(frames[0], rs, cfg, *cal), n)
+
+
+def test_phase_to_height_constants_variant(pkg, cal):
+    """The constants of the reference's offline calibrator (Code/phase_to_height.py:63, :115, no debug_ramp): ROI erosion, a wider
+    frontier band and no plane pre-removal, scaled to 224: same parity bar as the default configuration."""
+    n = 224
+    cfg = pkg.FtpConfig.scaled(n)
+    cfg.roi_erode_px = int(round(80 * n / 1182))
+    cfg.frontier_zero_band_px = int(round(300 * n / 1182))
+    cfg.plane_order_for_removal = 0
+    ref, sensor = _sensor(pkg, cal, n, cfg, 2, config=3)
+    frames = pkg.synth.deformed_batch(n, 7, 2, config=3)
+    out = sensor.predict_batch(frames)
+    torch.cuda.synchronize()
+    rs = O.make_reference_state(ref, *pkg.synth.roi_circle(n), cfg)
+    for b in range(2):
+        _check_frame(out, b, O.process_frame(frames[b], rs, cfg, *cal), n)

@@ -296,8 +296,8 @@ int vistaf_ftp_create(const vistaf_ftp_config *cfg, int h, int w, int cx, int cy
     if (h < 8 || w < 8 || max_batch < 1 || r < 1) return fail(VISTAF_E_INVALID, "bad geometry");
     if (height_curve->type < 0 || height_curve->type > 5 || force_curve->type < 0 || force_curve->type > 5)
         return fail(VISTAF_E_INVALID, "Unknown model type in calibration");
-    if (cfg->poly_order < 1 || cfg->poly_order > 2 || cfg->plane_order_for_removal < 1 || cfg->plane_order_for_removal > 2)
-        return fail(VISTAF_E_INVALID, "polynomial order must be 1 or 2");
+    if (cfg->poly_order < 1 || cfg->poly_order > 2 || cfg->plane_order_for_removal < 0 || cfg->plane_order_for_removal > 2)
+        return fail(VISTAF_E_INVALID, "polynomial order must be 1 or 2 (plane_order_for_removal: 0 = no pre-removal)");
     if (cfg->patch_half_width_bins < 3 && cfg->patch_half_width_bins != 0) {}
     int bwp = std::max(3, cfg->patch_half_width_bins);
     if (2 * bwp + 1 > 255) return fail(VISTAF_E_INVALID, "patch too wide");
@@ -583,7 +583,10 @@ int vistaf_ftp_predict_batch(vistaf_ftp_handle *hd, const void *d_frames, int fo
 
     // ---- plane removal + two-pass detrend (shape_ftp.py:1706, :1716-1751)
     if (timed) hipEventRecord(hd->ev[ST_DETREND], st);
-    launch_robust_polyfit(hd->unwrapped, hd->reliable, c.plane_order_for_removal, c.irls_iters, (float)c.irls_c, 500, hd->coef, hd->phase1, B, h, w, st);
+    if (c.plane_order_for_removal > 0)
+        launch_robust_polyfit(hd->unwrapped, hd->reliable, c.plane_order_for_removal, c.irls_iters, (float)c.irls_c, 500, hd->coef, hd->phase1, B, h, w, st);
+    else   // no debug_ramp (the constants of Code/phase_to_height.py): the unwrapped phase goes to the detrend as it is
+        HIPCHK(hipMemcpyAsync(hd->phase1, hd->unwrapped, (size_t)B * P * sizeof(float), hipMemcpyDeviceToDevice, st));
     launch_robust_polyfit(hd->phase1, hd->reliable, c.poly_order, c.irls_iters, (float)c.irls_c, 200, hd->coef, hd->resid0, B, h, w, st);
     launch_select(hd->resid0, hd->reliable, (size_t)P, nullptr, true, hd->req_contact, 3, hd->thr3, nullptr, B, P, st);
     launch_contact_mask(hd->resid0, hd->reliable, hd->thr3, hd->rel_count, hd->contact_count, (float)c.min_contact_frac, (float)c.max_contact_frac,
