@@ -22,6 +22,7 @@
 //   * the (2r+1)^2 estimator terms are accumulated per lane over the 64-neighbour chunks and reduced once.
 #include <cstdio>
 #include "kernels.hpp"
+#include <type_traits>
 #include "telea_common.hpp"
 
 namespace vf {
@@ -118,21 +119,58 @@ __device__ inline bool wn_march(float *__restrict__ img, const uint8_t *__restri
     WQ q;
     q.e = qe; q.hotL = hotL; q.ovf = 0; q.cap = qcap;
     wq_init(q);
-    unsigned long long np1 = 0, np2 = 0, nfill = 0;
+    unsigned long long np1 = 0, np2 = 0, nfill = 0, ns1 = 0;
     // ---- pass 1: outside T field (icvCalcFMM, negate); seeds pop first in raster order, then the queue.
     // States here are those of OpenCV's `out` mask: ring = INSIDE, hole and everything else KNOWN.
     {
         const TeleaOutsideConsts oc = telea_outside_consts(lane, ww);
-        for (int phase = 0; phase < 2 && !q.ovf; phase++) {
-            if (phase == 1) WSTAMP(3);
-            int base = 0;
-            unsigned long long pend = 0;
-            for (;;) {
-                int p = phase == 0 ? wn_next_seed(f, cells, base, pend, lane) : wq_pop(q);
-                if (p < 0) break;
-                np1++;
-                telea_pop_outside(win, oc, p, phase == 0, lane, [&](float T_, int idx_) { wq_push(q, T_, idx_, lane); });
+        const uint32_t magic_ww = (uint32_t)(0x100000000ull / (unsigned)ww) + 1u;        // cell / ww == umulhi(cell, magic) for cell < 2^16
+        // seeds (raster order): up to 4 per step out of the current 64-cell chunk
+        WSTAMP(3);
+        for (int base = 0; base < cells && !q.ovf; base += 64) {
+            const int li = base + lane;
+            unsigned long long pend = __ballot(li < cells && (f[li] & W_SEED));
+            while (pend && !q.ovf) {
+                int cand[4];
+                unsigned long long rest = pend;
+#pragma unroll
+                for (int k = 0; k < 4; k++) { cand[k] = base + (int)(__ffsll((long long)rest) - 1); rest &= rest - 1ull; }    // ffs(0) - 1 = -1: masked by n
+                const int np = __popcll(pend);
+                const uint32_t candT[4] = {0u, 0u, 0u, 0u};
+                const int m = telea_pop_outside4(win, oc, cand, candT, telea_outside_prefix(cand, np < 4 ? np : 4, ww, magic_ww), true, lane,
+                                                 [](int) {}, [&](float T_, int idx_) { wq_push<false>(q, T_, idx_, lane); });
+                pend &= pend - 1ull;
+                if (m > 1) pend &= pend - 1ull;
+                if (m > 2) pend &= pend - 1ull;
+                if (m > 3) pend &= pend - 1ull;
+                np1 += m;
+                ns1++;
             }
+        }
+        // queue: the next <= 4 entries in order are the first words of the cold run once no hot key precedes them
+        while (!q.ovf) {
+            int cold_n = q.tail - q.head;
+            if (cold_n == 0 && q.nh == 0) break;
+            const int g = lane >> 4;
+            unsigned long long wv = g < cold_n ? q.e[q.head + g] : 0ull;
+            const uint32_t t3 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wv >> 32), 48);
+            if (q.nh > 0 && (cold_n < 4 || q.h0 < t3)) {
+                wq_merge<false>(q, lane);
+                cold_n = q.tail - q.head;
+                wv = g < cold_n ? q.e[q.head + g] : 0ull;
+            }
+            if (q.ovf) break;
+            const int n = cold_n < 4 ? cold_n : 4;
+            int cand[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) cand[k] = __builtin_amdgcn_readlane((int)(uint32_t)wv, 16 * k);
+            uint32_t candT[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) candT[k] = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wv >> 32), 16 * k);
+            const int m = telea_pop_outside4(win, oc, cand, candT, telea_outside_prefix(cand, n, ww, magic_ww), false, lane,
+                                             [&](int mc) { q.head += mc; }, [&](float T_, int idx_) { wq_push<false>(q, T_, idx_, lane); });
+            np1 += m;
+            ns1++;
         }
     }
     WSTAMP(4);
@@ -148,19 +186,23 @@ __device__ inline bool wn_march(float *__restrict__ img, const uint8_t *__restri
     wq_init(q);
     const TeleaMarchConsts mc = telea_march_consts(lane, ww, range);
     WSTAMP(5);
-    for (int phase = 0; phase < 2 && !q.ovf; phase++) {
-        if (phase == 1) WSTAMP(6);
-        int base = 0;
-        unsigned long long pend = 0;
-        for (;;) {
-            int p = phase == 0 ? wn_next_seed(f, cells, base, pend, lane) : wq_pop(q);
-            if (p < 0) break;
-            np2++;
-            nfill += telea_pop_march(win, mc, p, phase == 1, lane, [&](float T_, int idx_) { wq_push(q, T_, idx_, lane); });
+    auto march = [&](auto small) {
+        for (int phase = 0; phase < 2 && !q.ovf; phase++) {
+            if (phase == 1) WSTAMP(6);
+            int base = 0;
+            unsigned long long pend = 0;
+            for (;;) {
+                int p = phase == 0 ? wn_next_seed(f, cells, base, pend, lane) : wq_pop(q);
+                if (p < 0) break;
+                np2++;
+                nfill += telea_pop_march<decltype(small)::value>(win, mc, p, phase == 1, lane, [&](float T_, int idx_) { wq_push(q, T_, idx_, lane); });
+            }
         }
-    }
+    };
+    if (mc.nn <= 64) march(std::true_type{});
+    else march(std::false_type{});
     WSTAMP(7);
-    if (!CL && lane == 0 && b < 1024) { g_win_dbg[b][8] = (np1 << 32) | np2; g_win_dbg[b][9] = (nfill << 32) | (unsigned)cells; }
+    if (!CL && lane == 0 && b < 1024) { g_win_dbg[b][8] = (np1 << 32) | np2; g_win_dbg[b][9] = (nfill << 32) | (unsigned)cells; g_win_dbg[b][10] = ns1; }
     if (q.ovf) return false;
     // ---- write back the hole pixels
     for (int r = 0; r < wh; r++) {
@@ -250,8 +292,8 @@ void telea_window_debug_dump(int B)
     for (int b : {0, worst}) {
         unsigned long long *x = hbuf[b];
         printf("[telea window dbg] frame %d cycles: load %llu | ring %llu | p1 seeds %llu | p1 queue %llu | negate %llu | p2 seeds %llu | p2 queue %llu | "
-               "pops %llu / %llu | filled %llu | cells %llu | mean total over frames %.0f\n", b, x[1] - x[0], x[2] - x[1], x[3] - x[2], x[4] - x[3], x[5] - x[4], x[6] - x[5], x[7] - x[6],
-               x[8] >> 32, x[8] & 0xffffffffull, x[9] >> 32, x[9] & 0xffffffffull, mean);
+               "pops %llu (in %llu steps) / %llu | filled %llu | cells %llu | mean total over frames %.0f\n", b, x[1] - x[0], x[2] - x[1], x[3] - x[2], x[4] - x[3], x[5] - x[4], x[6] - x[5], x[7] - x[6],
+               x[8] >> 32, x[10], x[8] & 0xffffffffull, x[9] >> 32, x[9] & 0xffffffffull, mean);
     }
 }
 

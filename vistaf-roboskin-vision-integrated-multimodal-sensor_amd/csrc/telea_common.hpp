@@ -211,8 +211,8 @@ __device__ inline TeleaMarchConsts telea_march_consts(int lane, int ww, int rang
     for (int c2 = 0; c2 < 2; c2++) {
         int nidx = c2 * 64 + lane;
         int dk = nidx / c.side - range, dl = nidx % c.side - range;
-        c.off[c2] = dk * ww + dl;
         c.on[c2] = nidx < c.nn && (dl * dl + dk * dk <= c.r2);
+        c.off[c2] = c.on[c2] ? dk * ww + dl : 0;              // lanes that are off may read, unused, the centre pixel
         float ry = (float)(-dk), rx = (float)(-dl);
         c.rx[c2] = rx; c.ry[c2] = ry;
         float len2 = __fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry));
@@ -254,9 +254,99 @@ __device__ __attribute__((always_inline)) inline void telea_pop_outside(const Te
     }
 }
 
+// Up to FOUR pops of the outside pass at once.  A pop of this pass only uses 16 lanes (4 neighbours x 4 quadrants), so lane
+// group g = lane >> 4 takes the g-th of the next entries IN QUEUE ORDER, as long as the one-at-a-time loop would have popped
+// exactly these entries one after the other with the same data:
+//  * a pop writes within Manhattan distance 1 of its pixel and reads within 2, so two entries at distance >= 4 do not see
+//    each other's writes (telea_outside_prefix cuts the candidate list at the first pair that is closer);
+//  * an entry pushed by an earlier member of the batch must not sort before a later member (T_new < T_member would put the new
+//    entry first; T_new == T_member keeps the member first, FIFO): the batch is cut there before anything is written.
+// Pushes go group by group, neighbour by neighbour -- the push order of the sequential loop -- so the queue contents, the FIFO
+// order among equal T and every later pop are those of the sequential march: results are bit-identical.
+// `cells` = the candidate cells (wave-uniform), n = how many are valid; returns the longest admissible prefix by distance.
+__device__ inline int telea_outside_prefix(const int (&cells)[4], int n, int ww, uint32_t magic_ww)
+{
+    int r[4], c[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { r[i] = (int)__umulhi((uint32_t)cells[i], magic_ww); c[i] = cells[i] - r[i] * ww; }
+    int m = 1;
+#pragma unroll
+    for (int j = 1; j < 4; j++) {
+        bool clash = false;
+#pragma unroll
+        for (int i = 0; i < j; i++) { int dr = r[i] - r[j], dc = c[i] - c[j]; clash = clash || (abs(dr) + abs(dc) < 4); }
+        if (m == j && j < n && !clash) m = j + 1;
+    }
+    return m;
+}
+// cellT = the float bits of the candidates' T (all 0 for the seeds, which never wait for a push); commit(k) removes the k entries
+// from the queue.  Returns the number of entries popped (1..m).
+template <class Commit, class Push>
+__device__ __attribute__((always_inline)) inline int telea_pop_outside4(const TeleaWin &win, const TeleaOutsideConsts &oc, const int (&cells)[4],
+                                                                        const uint32_t (&cellT)[4], int m, bool seed, int lane, Commit commit, Push push)
+{
+    float *t = win.t;
+    uint8_t *f = win.f;
+    const int dn = oc.dn, d1 = oc.d1, d2 = oc.d2;
+    const int g = lane >> 4;
+    const int p = g == 0 ? cells[0] : g == 1 ? cells[1] : g == 2 ? cells[2] : cells[3];
+    const int pn = p + dn;
+    const bool ok = g < m && (f[pn] & W_ST) == W_INSIDE;
+    unsigned long long okb = __ballot(ok);
+    if (okb) {
+        float dist = 0.f;
+        if (ok) {
+            const int p1 = pn + d1, p2 = pn + d2;
+            float a11 = t[p1], a22 = t[p2];
+            uint8_t f1 = f[p1], f2 = f[p2];           // p itself may be among them: BAND now, CHANGE after the pop -- not INSIDE either way
+            dist = wn_solve(a11, a22, (f1 & W_ST) != W_INSIDE, (f2 & W_ST) != W_INSIDE);
+        }
+        float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dist), 0xB1, 0xf, 0xf, false)); dist = o < dist ? o : dist;
+        o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dist), 0x4E, 0xf, 0xf, false)); dist = o < dist ? o : dist;
+        if (m > 1) {
+            // smallest T pushed by each group (row = 16 lanes = one group); T >= 0, so the float bits order like the values
+            uint32_t gm = ok ? __float_as_uint(dist) : 0x7f800000u, og;
+            og = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)gm, 0x141, 0xf, 0xf, false); gm = og < gm ? og : gm;      // row_half_mirror
+            og = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)gm, 0x140, 0xf, 0xf, false); gm = og < gm ? og : gm;      // row_mirror
+            uint32_t run = (uint32_t)__builtin_amdgcn_readlane((int)gm, 0);
+            int mc = 1;
+            if (cellT[1] <= run) {
+                mc = 2;
+                const uint32_t g1 = (uint32_t)__builtin_amdgcn_readlane((int)gm, 16);
+                run = g1 < run ? g1 : run;
+                if (m > 2 && cellT[2] <= run) {
+                    mc = 3;
+                    const uint32_t g2 = (uint32_t)__builtin_amdgcn_readlane((int)gm, 32);
+                    run = g2 < run ? g2 : run;
+                    if (m > 3 && cellT[3] <= run) mc = 4;
+                }
+            }
+            m = mc;
+            okb &= m >= 4 ? ~0ull : (1ull << (16 * m)) - 1ull;
+        }
+        commit(m);                            // the m entries leave the queue before their pushes enter it
+        if (g < m && (lane & 15) == 0) f[p] = (uint8_t)(seed ? (W_SEED | W_CHANGE) : W_CHANGE);   // ring pixels carry no other bit that matters
+        // pushes in the order of the sequential loop: pop by pop, neighbour by neighbour = ascending lane among the quad leaders
+        unsigned long long pb = okb & 0x1111111111111111ull;
+        while (pb) {
+            const int l = __ffsll((long long)pb) - 1;
+            pb &= pb - 1ull;
+            const float dk = wn_lane_f(dist, l);
+            const int pk = __builtin_amdgcn_readlane(pn, l);
+            if (lane == 0) { t[pk] = dk; f[pk] = W_BAND; }
+            push(dk, pk);
+        }
+    } else {
+        commit(m);
+        if (g < m && (lane & 15) == 0) f[p] = (uint8_t)(seed ? (W_SEED | W_CHANGE) : W_CHANGE);
+    }
+    return m;
+}
+
 // Telea march (icvTeleaInpaintFMM): pop p, fill every 4-neighbour that is still INSIDE and push it.  Returns the number of
 // pixels filled.
-template <class Push>
+// SMALL: the estimator window fits one 64-lane chunk ((2 * range + 1)^2 <= 64), the case of every shipped configuration.
+template <bool SMALL, class Push>
 __device__ __attribute__((always_inline)) inline int telea_pop_march(const TeleaWin &win, const TeleaMarchConsts &mc, int p, bool from_queue, int lane,
                                                                      Push push)
 {
@@ -275,6 +365,61 @@ __device__ __attribute__((always_inline)) inline int telea_pop_march(const Telea
         todo &= todo - 1;
         const int pi = p + (qn == 0 ? -ww : qn == 1 ? -1 : qn == 2 ? ww : 1);
         nfill++;
+        if constexpr (SMALL) {
+            // One estimator chunk (side^2 <= 64), written as ONE basic block: on a lone wave a taken branch costs tens of cycles and a
+            // dependent instruction ~9, so every LDS read is issued up front (the T word read at pi itself is the stale one, but
+            // pi is INSIDE and never enters the sums), every condition is a per-lane select, and the quadrant solve (an f64 chain)
+            // overlaps the image-gradient terms of the estimator.  Lanes that are off read, unused, around pi itself.
+            const uint8_t f4 = f[pi + d4];
+            const float t4 = t[pi + d4];
+            const int pk = pi + h_off[0];
+            const uint8_t f0 = f[pk], fr = f[pk + 1], fl = f[pk - 1], fd = f[pk + ww], fu = f[pk - ww];
+            const float tk = t[pk];
+            // OpenCV's index shifts at the first / last image row / column (km, kp, lm, lp): all 0 away from the image border
+            const int sk = (fu >> 4) & 1, sK = (fd >> 4) & 1, sl = (fl >> 4) & 1, sL = (fr >> 4) & 1;
+            const int rowm = pk + (sk ? ww : 0);
+            const float vC = im[rowm + sl], vA = im[rowm + 1 - sL], vB = im[rowm + sl - 1], vD = im[rowm - sL];
+            const float vE = im[pk + (sK ? 0 : ww) + sl], vF = im[rowm - ww + sl], vG = im[pk - (sK ? ww : 0) + sl];
+            const float tu = wn_lane_f(t4, 0), tl = wn_lane_f(t4, 1), td = wn_lane_f(t4, 2), tr = wn_lane_f(t4, 3);
+            // the neighbour states are wave-uniform; as scalar conditions every select below would become a branch, so they are
+            // handed to the compiler as per-lane values
+            unsigned kv = (unsigned)__ballot((f4 & W_ST) != W_INSIDE) & 0xf;
+            asm volatile("" : "+v"(kv));
+            const bool ku = kv & 1, kl = kv & 2, kd = kv & 4, kr = kv & 8;
+            const int qd = lane & 3;
+            float sq = wn_solve((qd & 1) ? td : tu, (qd & 2) ? tr : tl, (qd & 1) ? kd : ku, (qd & 2) ? kr : kl);
+            float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sq), 0xB1, 0xf, 0xf, false)); sq = o < sq ? o : sq;
+            o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sq), 0x4E, 0xf, 0xf, false)); sq = o < sq ? o : sq;
+            const float tc = wn_lane_f(sq, 0);
+            if (lane == 0) t[pi] = tc;
+            // (all alternatives are evaluated, then selected: nested conditional expressions would come back as branches)
+            const float gx2 = __fmul_rn(__fsub_rn(tr, tl), 0.5f), gxr = __fsub_rn(tr, tc), gxl = __fsub_rn(tc, tl);
+            const float gy2 = __fmul_rn(__fsub_rn(td, tu), 0.5f), gyd = __fsub_rn(td, tc), gyu = __fsub_rn(tc, tu);
+            const float gtx_r = kl ? gx2 : gxr, gtx_n = kl ? gxl : 0.f, gtx = kr ? gtx_r : gtx_n;
+            const float gty_d = ku ? gy2 : gyd, gty_n = ku ? gyu : 0.f, gty = kd ? gty_d : gty_n;
+            const float rx = h_rx[0], ry = h_ry[0];
+            const bool use = (int)h_on[0] & (int)((f0 & W_BORDER) == 0) & (int)((f0 & W_ST) != W_INSIDE);
+            const float lev = __fdiv_rn(1.0f, __fadd_rn(1.0f, fabsf(__fsub_rn(tk, tc))));
+            float dir = __fadd_rn(__fmul_rn(rx, gtx), __fmul_rn(ry, gty));
+            dir = fabsf(dir) <= 0.01f ? 0.000001f : dir;          // float(0.01) < 0.01: same set of floats as the double compare
+            const float wgt = fabsf(__fmul_rn(__fmul_rn(h_dstw[0], lev), dir));
+            const bool nr = (fr & W_ST) != W_INSIDE, nl = (fl & W_ST) != W_INSIDE, nd = (fd & W_ST) != W_INSIDE, nu = (fu & W_ST) != W_INSIDE;
+            const float ix2 = __fmul_rn(__fsub_rn(vA, vB), 2.0f), ixr = __fsub_rn(vA, vC), ixl = __fsub_rn(vD, vB);
+            const float iy2 = __fmul_rn(__fsub_rn(vE, vF), 2.0f), iyd = __fsub_rn(vE, vC), iyu = __fsub_rn(vG, vF);
+            const float gix_r = nl ? ix2 : ixr, gix_n = nl ? ixl : 0.f, gix = nr ? gix_r : gix_n;
+            const float giy_d = nu ? iy2 : iyd, giy_n = nu ? iyu : 0.f, giy = nd ? giy_d : giy_n;
+            const float z = 0.f;                                  // the sums start at +0, as in the chunk loop of the general variant
+            const float aIa = use ? __fadd_rn(z, __fmul_rn(wgt, vC)) : z;
+            const float aJx = use ? __fsub_rn(z, __fmul_rn(wgt, __fmul_rn(gix, rx))) : z;
+            const float aJy = use ? __fsub_rn(z, __fmul_rn(wgt, __fmul_rn(giy, ry))) : z;
+            const float aS = use ? __fadd_rn(z, wgt) : z;
+            const float Ia = wn_dpp_sum(aIa), Jx = wn_dpp_sum(aJx), Jy = wn_dpp_sum(aJy), s = __fadd_rn(wn_dpp_sum(aS), 1.0e-20f);
+            const float nrm = __fadd_rn(__fsqrt_rn(__fadd_rn(__fmul_rn(Jx, Jx), __fmul_rn(Jy, Jy))), 1.0e-20f);
+            const float val = __fadd_rn(__fdiv_rn(Ia, s), __fdiv_rn(__fadd_rn(Jx, Jy), nrm));
+            if (lane == 0) { im[pi] = val; f[pi] = (uint8_t)(W_HOLE | W_BAND); }
+            push(tc, pi);
+            continue;
+        }
         // (flag, T) of pi's up / left / down / right neighbours on lanes 0..3, shared by all lanes
         const uint8_t f4 = f[pi + d4];
         const float t4 = t[pi + d4];
