@@ -71,7 +71,8 @@ struct FitCtx {
 template <int N>
 __device__ inline bool chol_solve(double (&A)[6][6], double (&rhs)[6])
 {
-    double L[N][N];
+    // one reciprocal per pivot (the 27 divisions of the textbook form are a long dependent chain on the one thread that solves)
+    double L[N][N], inv[N];
 #pragma unroll
     for (int i = 0; i < N; i++) {
 #pragma unroll
@@ -79,8 +80,8 @@ __device__ inline bool chol_solve(double (&A)[6][6], double (&rhs)[6])
             double s = A[i][j];
 #pragma unroll
             for (int k = 0; k < j; k++) s -= L[i][k] * L[j][k];
-            if (i == j) { if (!(s > 0.0)) return false; L[i][i] = sqrt(s); }
-            else L[i][j] = s / L[j][j];
+            if (i == j) { if (!(s > 0.0)) return false; L[i][i] = sqrt(s); inv[i] = 1.0 / L[i][i]; }
+            else L[i][j] = s * inv[j];
         }
     }
 #pragma unroll
@@ -88,14 +89,14 @@ __device__ inline bool chol_solve(double (&A)[6][6], double (&rhs)[6])
         double s = rhs[i];
 #pragma unroll
         for (int k = 0; k < i; k++) s -= L[i][k] * rhs[k];
-        rhs[i] = s / L[i][i];
+        rhs[i] = s * inv[i];
     }
 #pragma unroll
     for (int i = N - 1; i >= 0; i--) {
         double s = rhs[i];
 #pragma unroll
         for (int k = i + 1; k < N; k++) s -= L[k][i] * rhs[k];
-        rhs[i] = s / L[i][i];
+        rhs[i] = s * inv[i];
     }
     return true;
 }

@@ -58,10 +58,11 @@ __device__ inline uint32_t wave_scan_add(uint32_t v)
 }
 
 // Finds keys of rank k and k+1 (ascending, 0-based) among the n valid elements.
-// get(i, key) -> bool valid.  n must be > 0 and k < n.  Result in all threads.
-template <class F>
-__device__ inline void block_select2(F get, int P, uint32_t n, uint32_t k, SelShared &sh, uint32_t kmin, uint32_t kmax,
-                                     uint32_t &key_a, uint32_t &key_b)
+// each(body) calls body(key) for every valid element of this thread (the same elements on every call).
+// n must be > 0 and k < n.  Result in all threads.
+template <class Each>
+__device__ __attribute__((always_inline)) inline void block_select2_each(Each each, uint32_t n, uint32_t k, SelShared &sh, uint32_t kmin, uint32_t kmax,
+                                                                         uint32_t &key_a, uint32_t &key_b)
 {
     const int tid = threadIdx.x;
     uint32_t lo = kmin, hi = kmax, below = 0;
@@ -73,7 +74,7 @@ __device__ inline void block_select2(F get, int P, uint32_t n, uint32_t k, SelSh
         int shift = bits > 11 ? bits - 11 : 0;
         for (int i = tid; i < SEL_NB; i += SEL_T) sh.hist[i] = 0;
         __syncthreads();
-        sel_foreach(get, P, [&](uint32_t key) { if (key >= lo && key <= hi) atomicAdd(&sh.hist[(key - lo) >> shift], 1u); });
+        each([&](uint32_t key) { if (key >= lo && key <= hi) atomicAdd(&sh.hist[(key - lo) >> shift], 1u); });
         __syncthreads();
         // locate the bucket holding rank (k - below): each thread owns 2 buckets
         uint32_t want = k - below;
@@ -104,19 +105,46 @@ __device__ inline void block_select2(F get, int P, uint32_t n, uint32_t k, SelSh
             // collect candidates of this bucket, rank by counting
             if (tid == 0) sh.s_ncand = 0;
             __syncthreads();
-            sel_foreach(get, P, [&](uint32_t key) {
-                if (key >= lo && key <= hi) { uint32_t pos = atomicAdd(&sh.s_ncand, 1u); if (pos < SEL_CAND) sh.cand[pos] = key; }
+            each([&](uint32_t key) {
+                // one counter update per wave and visit: the lanes holding a candidate take consecutive slots
+                const bool in = key >= lo && key <= hi;
+                const unsigned long long mk = __ballot(in);
+                if (in) {
+                    const int ln = threadIdx.x & 63, leader = __ffsll((long long)mk) - 1;
+                    uint32_t base = 0;
+                    if (ln == leader) base = atomicAdd(&sh.s_ncand, (uint32_t)__popcll(mk));
+                    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+                    const uint32_t pos = base + (uint32_t)__popcll(mk & ((1ull << ln) - 1ull));
+                    if (pos < SEL_CAND) sh.cand[pos] = key;
+                }
             });
             __syncthreads();
             uint32_t m = sh.s_ncand;
-            uint32_t want2 = k - below;
+            const uint32_t want2 = k - below;
             if (tid == 0) { sh.s_found = 0; }
             __syncthreads();
-            if ((uint32_t)tid < m) {
-                uint32_t c = sh.cand[tid], r = 0;
-                for (uint32_t j = 0; j < m; j++) { uint32_t o = sh.cand[j]; r += (o < c) || (o == c && j < (uint32_t)tid); }
-                if (r == want2) sh.s_a = c;
-                if (r == want2 + 1) { sh.s_b = c; sh.s_found = 1; }
+            if (m > SEL_CAND) m = SEL_CAND;                                  // cannot happen (cnt <= SEL_CAND); keeps the indices in range
+            // sort the candidates (bitonic network in LDS, padded with the largest key to a power of two >= 64): the two order
+            // statistics are then read off by index.  Partners closer than 64 live in the same wave, whose LDS operations execute
+            // in order, so only the wider exchanges and the start of a new merge round need a workgroup barrier.
+            const uint32_t np2 = m <= 64u ? 64u : 1u << (32 - __clz(m - 1u));
+            if ((uint32_t)tid >= m && (uint32_t)tid < np2) sh.cand[tid] = 0xFFFFFFFFu;
+            __syncthreads();
+            for (uint32_t k2 = 2; k2 <= np2; k2 <<= 1) {
+                for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+                    const uint32_t ixj = (uint32_t)tid ^ j;
+                    if ((uint32_t)tid < np2 && ixj > (uint32_t)tid) {
+                        const uint32_t x = sh.cand[tid], y = sh.cand[ixj];
+                        const bool up = ((uint32_t)tid & k2) == 0u;
+                        if ((x > y) == up) { sh.cand[tid] = y; sh.cand[ixj] = x; }
+                    }
+                    if (j >= 64u || (j == 1u && k2 >= 64u)) __syncthreads();
+                    else __builtin_amdgcn_wave_barrier();
+                }
+            }
+            if (tid == 0) {
+                sh.s_a = sh.cand[want2];
+                if (want2 + 1 < m) { sh.s_b = sh.cand[want2 + 1]; sh.s_found = 1; }
             }
             __syncthreads();
             a = sh.s_a;
@@ -128,7 +156,7 @@ __device__ inline void block_select2(F get, int P, uint32_t n, uint32_t k, SelSh
     {
         uint32_t le = 0;
         unsigned long long nxt = ~0ull;
-        sel_foreach(get, P, [&](uint32_t key) { le += key <= a; if (key > a && (unsigned long long)key < nxt) nxt = key; });
+        each([&](uint32_t key) { le += key <= a; if (key > a && (unsigned long long)key < nxt) nxt = key; });
         __syncthreads();
         uint32_t tot = block_sum<uint32_t>(le, sh.wsum);
         unsigned long long mn = block_min_u64(nxt, sh.red64);
@@ -136,6 +164,14 @@ __device__ inline void block_select2(F get, int P, uint32_t n, uint32_t k, SelSh
         __syncthreads();
     }
     key_a = a; key_b = b;
+}
+
+// get(i, key) -> bool valid over the P elements of a plane
+template <class F>
+__device__ inline void block_select2(F get, int P, uint32_t n, uint32_t k, SelShared &sh, uint32_t kmin, uint32_t kmax,
+                                     uint32_t &key_a, uint32_t &key_b)
+{
+    block_select2_each([&](auto body) { sel_foreach(get, P, body); }, n, k, sh, kmin, kmax, key_a, key_b);
 }
 
 // count / min / max of valid keys
@@ -191,15 +227,19 @@ __device__ inline float block_percentile(F get, int P, float q32, SelShared &sh,
 }
 
 // np.median of valid elements (mean of the two middle values in float32 for even n)
-template <class F>
-__device__ inline float block_median(F get, int P, SelShared &sh, uint32_t n, uint32_t kmin, uint32_t kmax)
+template <class Each>
+__device__ __attribute__((always_inline)) inline float block_median_each(Each each, SelShared &sh, uint32_t n, uint32_t kmin, uint32_t kmax)
 {
     if (n == 0) return __uint_as_float(0x7fc00000u);
     if (n == 1) return key2f(kmin);
     uint32_t ka, kb;
-    if (n & 1u) { block_select2(get, P, n, (n - 1) / 2, sh, kmin, kmax, ka, kb); return key2f(ka); }
-    block_select2(get, P, n, n / 2 - 1, sh, kmin, kmax, ka, kb);
-    return __fdiv_rn(__fadd_rn(key2f(ka), key2f(kb)), 2.0f);
+    block_select2_each(each, n, (n & 1u) ? (n - 1) / 2 : n / 2 - 1, sh, kmin, kmax, ka, kb);
+    return (n & 1u) ? key2f(ka) : __fdiv_rn(__fadd_rn(key2f(ka), key2f(kb)), 2.0f);
+}
+template <class F>
+__device__ inline float block_median(F get, int P, SelShared &sh, uint32_t n, uint32_t kmin, uint32_t kmax)
+{
+    return block_median_each([&](auto body) { sel_foreach(get, P, body); }, sh, n, kmin, kmax);
 }
 
 }  // namespace vf
