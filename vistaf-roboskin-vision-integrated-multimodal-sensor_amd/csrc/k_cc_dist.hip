@@ -193,7 +193,7 @@ __global__ __launch_bounds__(1024) void k_cc_largest(const int32_t *__restrict__
     constexpr int U = 4;                    // independent loads in flight per thread (the loops are bound by memory round trips)
     const int T = blockDim.x;
     for (int p = threadIdx.x; p < P; p += T) A[p] = 0;
-    __threadfence();
+    __threadfence_block();      // one workgroup per frame: no agent-scope write-back of the L2
     __syncthreads();
     int Pr = ((P + U * 1024 - 1) / (U * 1024)) * (U * 1024);
     // run-length accumulation per wave: consecutive tiles mostly belong to the same (large) component, and an atomic per tile on one
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(1024) void k_cc_largest(const int32_t *__restrict__
         }
     }
     if (run_root >= 0 && lane == 0) atomicAdd(&A[run_root], run_cnt);
-    __threadfence();
+    __threadfence_block();      // one workgroup per frame: no agent-scope write-back of the L2
     __syncthreads();
     unsigned long long best = 0;
     for (int p0 = threadIdx.x; p0 < P; p0 += U * T) {

@@ -56,8 +56,10 @@ __device__ inline uint32_t dpp_max8_u32(uint32_t v)
 // 64-element tiles (coalesced, L1-bypassing loads of data other waves wrote in the previous pass).
 // Counting uses a per-wave 2048-bin LDS histogram (16 x 8 KB); the stable scatter ranks a lane among the lanes of its
 // tile that share its digit with eleven ballots (peer mask) + mbcnt.
-__device__ inline uint32_t ld_u32c(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ inline unsigned long long ld_u64c(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Every exchange through global memory in this kernel is between waves of ONE workgroup (one frame): workgroup scope is all the
+// ordering it needs.  (Agent scope would write back and invalidate the XCD's whole L2 at every fence: buffer_wbl2 / buffer_inv sc1.)
+__device__ inline uint32_t ld_u32c(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ inline unsigned long long ld_u64c(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 constexpr int RK_BITS = 11, RK_NB = 1 << RK_BITS;   // 3 passes of 11 bits over the 32-bit keys
 constexpr int RK_U = 4;        // 64-element tiles in flight per wave (independent loads issued together)
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(RK_T) void k_unwrap_rank(const float *__restrict__ 
         }
     }
     if (tid == 0 && n == 0) seed_out[b] = -1;
-    __threadfence();
+    __threadfence_block();
     __syncthreads();
     if (n == 0) return;
 
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(RK_T) void k_unwrap_rank(const float *__restrict__ 
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        __threadfence();
+        __threadfence_block();
         __syncthreads();
         unsigned long long *t = rs; rs = rd; rd = t;
     }
