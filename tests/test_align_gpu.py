@@ -113,3 +113,25 @@ def test_calibration_batch_job_driver(pkg, photos):
     stored = {"volume_cm3": 0.11378655442935222, "contact_area_mm2": 304.914771865451, "max_depth_mm": 1.1214957237243652}   # FINAL_E result.json
     for k, tol in (("volume_cm3", 2e-3), ("contact_area_mm2", 2e-3), ("max_depth_mm", 5e-4)):
         assert abs(rows[0][k] - stored[k]) <= tol * stored[k], k
+
+
+def test_phase_to_height_batch_job_driver(pkg, photos):
+    """N4, second calibrator: `calibrate.phase_to_height_rows` (photograph -> FtpAligner -> FtpSensor with the constants of
+    Code/phase_to_height.py -> row of calibration_results.csv) on the reference's own calibration photograph
+    `Force/Phase_to_height/Height_2mm_deformed.jpg` (tests/golden, a data file).  Expected: the stored row of the reference's
+    calibration_results.csv (tests/golden/ref_phase_to_height_results.csv): min_height_unitless -1.26027 at (722, 588); the CPU
+    oracle gives -1.25980 at (722, 589) (tests/golden/e2e_phase_to_height_report.json).  Tolerance: 1e-3 unitless (0.08 %), one
+    pixel on the location -- the same bar the oracle meets against the stored row."""
+    import csv
+    cal, neg = pkg.load_calibration(os.path.join(G, "calibration_phase_to_height.json"))
+    fm = pkg.load_force_calibration(os.path.join(G, "calibration_height_to_force.json"))["best_model"]
+    al = pkg.FtpAligner(photos[0], max_batch=2)
+    sensor = pkg.FtpSensor(al.reference_gray_crop, al.circle_crop, pkg.FtpConfig.phase_to_height(), cal, neg, fm, max_batch=2)
+    photo = _imread_bgr(os.path.join(G, "Height_2mm_deformed.jpg"))
+    rows = pkg.calibrate.phase_to_height_rows(al, sensor, [("Height_2mm_deformed.jpg", photo), ("Height_2mm_deformed.jpg", photo)], [2.07255, 2.07255], batch=2)
+    stored = [r for r in csv.DictReader(open(os.path.join(G, "ref_phase_to_height_results.csv"))) if r["file"] == "Height_2mm_deformed.jpg"][0]
+    assert rows[0] == rows[1]
+    r = rows[0]
+    assert r["file"] == stored["file"] and r["depth_mm"] == float(stored["depth_mm"]) and r["heightmap_figure"] == stored["heightmap_figure"]
+    assert abs(r["min_height_unitless"] - float(stored["min_height_unitless"])) <= 1e-3, r
+    assert abs(r["min_x"] - int(stored["min_x"])) <= 1 and abs(r["min_y"] - int(stored["min_y"])) <= 1, r

@@ -239,3 +239,50 @@ def test_force_calibration_fit_reproduces_the_stored_model(pkg):
     # prediction through the fitted model equals the C-ABI force curve
     v = 0.11378655442935222
     assert abs(float(pkg.calibrate.model_predict(b, v)) - pkg.predict_force_from_volume(b, v)) <= 1e-12
+
+
+def test_phase_to_height_fit_reproduces_the_stored_model(pkg, tmp_path):
+    """N4, second calibrator (Code/phase_to_height.py:1280-1383, :1491-1545): the four stored rows of the reference's
+    `Force/Phase_to_height/calibration_out/calibration_results.csv` (tests/golden/ref_phase_to_height_results.csv) give the stored
+    `calibration_model.json` (tests/golden/calibration_phase_to_height.json): same best model, parameters, RMSE ranking; the CSV
+    writer reproduces the stored file byte for byte; and the rows the path oracle computes from the four calibration photographs
+    (tests/golden/e2e_phase_to_height_report.json) give the same curve within the measurement differences."""
+    import csv
+    C = pkg.calibrate
+    stored_csv = os.path.join(G, "ref_phase_to_height_results.csv")
+    rows = list(csv.DictReader(open(stored_csv)))
+    assert [r["file"] for r in rows] == [f for f, _ in C.PHASE_TO_HEIGHT_SAMPLES]
+    assert [float(r["depth_mm"]) for r in rows] == [d for _, d in C.PHASE_TO_HEIGHT_SAMPLES]
+    stored = json.load(open(os.path.join(G, "calibration_phase_to_height.json")))
+    model = C.phase_to_height_model(rows, stored["reference_path"], stored["deformed_dir"], stored["output_dir"])
+    assert list(model.keys()) == list(stored.keys())
+    sb, mb = stored["best_model"], model["best_model"]
+    assert list(mb.keys()) == list(sb.keys()) and mb["type"] == sb["type"] == "hinge_saturating" and mb["n"] == sb["n"] == 4
+    for k in ("a", "b"):
+        assert abs(mb["params"][k] - sb["params"][k]) <= 1e-5 * abs(sb["params"][k]), (k, mb["params"][k], sb["params"][k])
+    assert abs(mb["params"]["c"] - sb["params"]["c"]) <= 1e-6          # the hinge sits at the origin (stored: -1.8e-9)
+    assert abs(mb["rmse"] - sb["rmse"]) <= 1e-6 and abs(mb["r2"] - sb["r2"]) <= 1e-5
+    assert [c["type"] for c in model["candidates_summary"]] == [c["type"] for c in stored["candidates_summary"]]
+    for cm, cs in zip(model["candidates_summary"], stored["candidates_summary"]):
+        assert abs(cm["rmse"] - cs["rmse"]) <= 1e-5 * max(1.0, cs["rmse"]), (cm, cs)
+    for k in ("use_negated_height_for_fit", "x_definition", "interpretation", "reference_path", "deformed_dir", "output_dir"):
+        assert model[k] == stored[k]
+    # the curve the path consumes: same millimetres over the range of the samples
+    x = np.linspace(0.0, 1.3, 50)
+    assert np.max(np.abs(C.model_predict(mb, x) - C.model_predict(sb, x))) <= 1e-5
+    # CSV writer: byte-identical to the stored file when fed the stored values
+    typed = [{"file": r["file"], "depth_mm": float(r["depth_mm"]), "min_height_unitless": float(r["min_height_unitless"]),
+              "min_x": int(r["min_x"]), "min_y": int(r["min_y"]), "heightmap_figure": r["heightmap_figure"]} for r in rows]
+    out = C.write_phase_to_height_csv(str(tmp_path / "calibration_results.csv"), typed)
+    assert open(out, "rb").read() == open(stored_csv, "rb").read()
+    # end to end: minima the path oracle measured on the four photographs -> the same curve within their differences (<= 6e-4 unitless)
+    rep = json.load(open(os.path.join(G, "e2e_phase_to_height_report.json")))
+    rows2 = [{"file": r["file"], "depth_mm": d, "min_height_unitless": r["min"]} for r, (_, d) in zip(rep, C.PHASE_TO_HEIGHT_SAMPLES)]
+    m2 = C.phase_to_height_model(rows2, "", "", "")["best_model"]
+    assert m2["type"] == "hinge_saturating"
+    assert np.max(np.abs(C.model_predict(m2, x) - C.model_predict(sb, x))) <= 5e-3          # mm, against 1.9-2.1 mm samples
+    # non-finite rows are skipped, fewer than two valid samples is an error (phase_to_height.py:1485-1492)
+    with pytest.raises(RuntimeError):
+        C.phase_to_height_model([{"file": "a", "depth_mm": 1.0, "min_height_unitless": float("nan")},
+                                 {"file": "b", "depth_mm": 2.0, "min_height_unitless": -1.0}], "", "", "")
+    assert pkg.FtpConfig.phase_to_height().roi_erode_px == 80 and pkg.FtpConfig.phase_to_height().plane_order_for_removal == 0

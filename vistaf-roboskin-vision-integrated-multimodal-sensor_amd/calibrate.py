@@ -16,6 +16,8 @@ from typing import Any, Callable, Dict, Iterable, List, Optional, Sequence, Tupl
 
 import numpy as np
 
+from .ftp import SCALAR_NAMES
+
 FORCE_LEVELS_N = (0.5, 1.0, 2.0, 3.0, 4.0, 6.0, 8.0, 10.0, 15.0, 20.0, 25.0, 30.0, 35.0, 40.0, 45.0)   # height_to_force.py:47
 IMAGES_PER_LEVEL = 5                                                                                     # :48
 PER_IMAGE_FIELDS = ("file", "force_N", "volume_cm3", "contact_area_mm2", "max_depth_mm", "mm_per_px", "estimated_grating_period_px",
@@ -212,4 +214,142 @@ def write_calibration_model(path: str, model: Dict[str, Any]) -> str:
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     with open(path, "w", encoding="utf-8") as f:
         json.dump(model, f, indent=2)
+    return path
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# phase_to_height calibration (Code/phase_to_height.py:1264-1383, :1441-1545): unitless height-map minimum -> mm
+
+PHASE_TO_HEIGHT_SAMPLES = (("Height_0.5mm_deformed.jpg", 1.90935), ("Height_1mm_deformed.jpg", 1.94770),
+                           ("Height_1.5mm_deformed.jpg", 2.01821), ("Height_2mm_deformed.jpg", 2.07255))      # :36-41
+PHASE_TO_HEIGHT_CANDIDATES = ("hinge_saturating", "growth")                                                     # :166
+PHASE_TO_HEIGHT_FIELDS = ("file", "depth_mm", "min_height_unitless", "min_x", "min_y", "heightmap_figure")      # :1517-1519
+
+
+def _p2h_growth(x, a, b):
+    return a * (np.exp(b * x) - 1.0)                                                                            # :1264-1266 (no clamp of x)
+
+
+def _p2h_equation(name: str, p: Dict[str, float]) -> str:
+    if name == "growth":
+        return f"y = {p['a']:.6g} * (exp({p['b']:.6g} x) - 1)"                                                  # :1299
+    return (f"y = {p['a']:.6g} * ((1-exp(-{p['b']:.6g}*max(x-{p['c']:.6g},0)))"
+            f" - (1-exp(-{p['b']:.6g}*max(0-{p['c']:.6g},0))))")                                                # :1327-1330
+
+
+def fit_phase_to_height_model(x, y, name: str, maxfev: int = 200000) -> Optional[Dict[str, Any]]:
+    """phase_to_height._fit_growth_curvefit / _fit_hinge_sat_curvefit (:1280-1333): `scipy.optimize.curve_fit` with the
+    reference's start values and bounds; None for negative samples or a failed fit."""
+    from scipy.optimize import curve_fit
+    x, y = np.asarray(x, float), np.asarray(y, float)
+    if np.any(x < 0) or np.any(y < 0):
+        return None
+    if name == "growth":
+        fn, names = _p2h_growth, ("a", "b")
+        p0 = [max(np.max(y), 1e-6), 1.0]
+        bounds = ([0.0, 0.0], [np.inf, np.inf])
+    elif name == "hinge_saturating":
+        fn, names = _hinge, ("a", "b", "c")
+        xmax = float(np.max(x)) if len(x) else 1.0
+        p0 = [max(np.max(y), 1e-6), 2.0, 0.2 * xmax]
+        bounds = ([0.0, 0.0, -0.5 * xmax], [np.inf, np.inf, 1.2 * xmax])
+    else:
+        raise ValueError(f"Unknown model type: {name}")
+    try:
+        popt, _ = curve_fit(fn, x, y, p0=p0, bounds=bounds, maxfev=int(maxfev))
+    except Exception:
+        return None
+    params = {k: float(v) for k, v in zip(names, popt)}
+    yhat = fn(x, *[params[k] for k in names])
+    return {"type": name, "params": params, "k": len(names), "yhat": yhat, "sse": float(np.sum((y - yhat) ** 2)), "rmse": _rmse(y, yhat),
+            "equation": _p2h_equation(name, params)}
+
+
+def _p2h_r2(y, yhat) -> float:
+    """phase_to_height.r2_score (:1064-1071)."""
+    y, yhat = np.asarray(y, float), np.asarray(yhat, float)
+    ss_res = float(np.sum((y - yhat) ** 2))
+    ss_tot = float(np.sum((y - np.mean(y)) ** 2))
+    return float("nan") if ss_tot <= 0 else float(1.0 - ss_res / ss_tot)
+
+
+def fit_phase_to_height_best(x, y, candidates: Sequence[str] = PHASE_TO_HEIGHT_CANDIDATES):
+    """phase_to_height.fit_best_model (:1335-1383): best = smallest RMSE; returns (best, summary sorted by RMSE)."""
+    x, y = np.asarray(x, float), np.asarray(y, float)
+    cands = []
+    for name in candidates:
+        m = fit_phase_to_height_model(x, y, name)
+        if m is None:
+            continue
+        m["r2"] = _p2h_r2(y, m["yhat"])
+        cands.append(m)
+    if not cands:
+        raise RuntimeError("No valid model candidates could be fit (check your x/y values).")
+    best = min(cands, key=lambda d: d["rmse"])
+    best["n"] = int(len(x))
+    summary = [{"type": c["type"], "rmse": float(c["rmse"]), "r2": float(c["r2"]), "sse": float(c["sse"])} for c in sorted(cands, key=lambda d: d["rmse"])]
+    return best, summary
+
+
+def phase_to_height_model(rows: Sequence[Dict[str, Any]], reference_path: str, deformed_dir: str, output_dir: str, use_negated_height: bool = True,
+                          anchor_origin: bool = False, origin_weight: int = 20, apply_origin_correction: bool = False) -> Dict[str, Any]:
+    """The dict of Phase_to_height/calibration_out/calibration_model.json (phase_to_height.py:1491-1545) from the per-image rows
+    (`file`, `depth_mm`, `min_height_unitless`); rows with a non-finite minimum are skipped as upstream."""
+    mins = np.array([float(r["min_height_unitless"]) for r in rows if np.isfinite(float(r["min_height_unitless"]))], float)
+    depths = np.array([float(r["depth_mm"]) for r in rows if np.isfinite(float(r["min_height_unitless"]))], float)
+    if len(mins) < 2:
+        raise RuntimeError("Not enough valid samples to fit a model (need at least 2).")
+    x = np.maximum(-mins if use_negated_height else mins, 0.0)
+    y = depths
+    if anchor_origin:
+        w = int(max(1, origin_weight))
+        x = np.concatenate((np.zeros(w, float), x))
+        y = np.concatenate((np.zeros(w, float), y))
+    best, summary = fit_phase_to_height_best(x, y)
+    out = {
+        "reference_path": reference_path, "deformed_dir": deformed_dir, "output_dir": output_dir,
+        "use_negated_height_for_fit": bool(use_negated_height),
+        "x_definition": "x = -min_height_unitless" if use_negated_height else "x = min_height_unitless",
+        "best_model": {"type": best["type"], "params": best["params"], "equation": best["equation"], "r2": float(best["r2"]),
+                       "rmse": float(best["rmse"]), "sse": float(best["sse"]), "n": int(best["n"])},
+        "candidates_summary": summary,
+        "interpretation": ("This model maps unitless heightmap values to mm. "
+                           "If use_negated_height_for_fit=true, it uses x=-height_unitless."),
+    }
+    if apply_origin_correction:
+        fn = _p2h_growth if best["type"] == "growth" else _hinge
+        out["best_model"]["origin_correction"] = float(fn(np.array([0.0]), *[best["params"][k] for k in (("a", "b") if best["type"] == "growth" else ("a", "b", "c"))])[0])
+    return out
+
+
+def phase_to_height_rows(aligner, sensor, frames_bgr: Iterable[Tuple[str, np.ndarray]], depths_mm: Sequence[float], batch: int = 4) -> List[Dict[str, Any]]:
+    """The per-image loop of phase_to_height.main (:1448-1489) as a batch job: `sensor` must be configured with the constants of
+    phase_to_height.py (FtpConfig.phase_to_height()); the row holds the minimum of the unitless height map inside the eroded ROI and
+    its location (compute_min_height, :1009-1020: np.nanargmin over the ROI, (x, y) in crop coordinates), which the C ABI returns in the
+    scalar record of every frame (`min_height_unitless`, `argmin_unitless_index`)."""
+    frames = list(frames_bgr)
+    rows: List[Dict[str, Any]] = []
+    for i0 in range(0, len(frames), batch):
+        chunk = frames[i0:i0 + batch]
+        crops = aligner.align(np.stack([f for _, f in chunk]))["aligned_gray"]
+        out = sensor.predict_batch(crops)
+        sc = out["scalars"].cpu().numpy()
+        i_min, i_arg = SCALAR_NAMES.index("min_height_unitless"), SCALAR_NAMES.index("argmin_unitless_index")
+        wcrop = int(out["height_map_mm"].shape[-1])
+        for j, (name, _f) in enumerate(chunk):
+            min_val = float(sc[j, i_min])
+            flat = int(sc[j, i_arg])
+            mx, my = (flat % wcrop, flat // wcrop) if np.isfinite(min_val) and flat >= 0 else (-1, -1)
+            stem = os.path.splitext(name)[0]
+            rows.append({"file": name, "depth_mm": float(depths_mm[i0 + j]), "min_height_unitless": min_val, "min_x": mx, "min_y": my,
+                         "heightmap_figure": os.path.join(stem, "heightmap.png")})
+    return rows
+
+
+def write_phase_to_height_csv(path: str, rows: Sequence[Dict[str, Any]]) -> str:
+    """calibration_results.csv exactly as upstream writes it (:1515-1520: f-string fields, no quoting)."""
+    with open(path, "w", encoding="utf-8") as f:
+        f.write(",".join(PHASE_TO_HEIGHT_FIELDS) + "\n")
+        for r in rows:
+            f.write(f"{r['file']},{r['depth_mm']},{r['min_height_unitless']},{r['min_x']},{r['min_y']},{r['heightmap_figure']}\n")
     return path

@@ -59,6 +59,16 @@ class FtpConfig:
         return cls()
 
     @classmethod
+    def phase_to_height(cls) -> "FtpConfig":
+        """The constants of the reference's offline calibrator Code/phase_to_height.py where they differ from shape_ftp.py:
+        ROI_ERODE_PX = 80 (:63), FRONTIER_ZERO_BAND_PX = 300 (:115), no debug_ramp plane pre-removal."""
+        c = cls()
+        c.roi_erode_px = 80
+        c.frontier_zero_band_px = 300
+        c.plane_order_for_removal = 0
+        return c
+
+    @classmethod
     def scaled(cls, n: int) -> "FtpConfig":
         """`scaled-n`: every *_PX constant of shape_ftp.py multiplied by n/1182:
         integer pixel counts rounded to the nearest int >= 1 (0 stays 0), Gaussian sigmas to one decimal
