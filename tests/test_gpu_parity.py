@@ -364,3 +364,37 @@ def test_phase_to_height_constants_variant(pkg, cal):
     rs = O.make_reference_state(ref, *pkg.synth.roi_circle(n), cfg)
     for b in range(2):
         _check_frame(out, b, O.process_frame(frames[b], rs, cfg, *cal), n)
+
+
+def test_inpaint_window_tier_against_sequential_tier_and_oracle_on_many_frames(pkg, cal):
+    """The window march executes up to four outside-pass pops per step and a straight-line fill (k_inpaint_win.hip); both must
+    leave the pop order of the one-at-a-time march untouched.  48 frames with different hole layouts through the window tier and
+    through the whole-frame sequential tier (`VISTAF_INPAINT=seq`, one pop per step): the inpainted planes must agree to the
+    float-sum tolerance (the tiers reduce the estimator sums in different orders; a pop out of order moves a filled pixel by far
+    more), and a sample of the frames is checked against the oracle's OpenCV-restated Telea."""
+    n, nb = 224, 48
+    cfg = pkg.FtpConfig.scaled(n)
+    ref, sensor = _sensor(pkg, cal, n, cfg, nb, config=3)
+    frames = np.concatenate([pkg.synth.deformed_batch(n, 200, nb // 2, config=3), pkg.synth.deformed_batch(n, 500, nb // 2, config=3, amp_scale=0.5)])
+    P = n * n
+    sensor.predict_batch(frames)
+    torch.cuda.synchronize()
+    img0 = sensor.intermediate("img", nb).cpu().numpy().reshape(nb, n, n).copy()
+    bad0 = sensor.intermediate("bad1", nb, torch.uint8).cpu().numpy().reshape(nb, n, n).copy()
+    os.environ["VISTAF_INPAINT"] = "seq"
+    try:
+        out = sensor.predict_batch(frames)
+        torch.cuda.synchronize()
+        img1 = sensor.intermediate("img", nb).cpu().numpy().reshape(nb, n, n).copy()
+        assert (out["status"].cpu().numpy() == 0).all()
+    finally:
+        os.environ.pop("VISTAF_INPAINT", None)
+    assert bad0.any(axis=(1, 2)).all()                                   # every frame has holes to fill
+    assert np.array_equal(img0[bad0 == 0], img1[bad0 == 0])              # known pixels untouched, bit for bit
+    assert float(np.abs(img0 - img1).max()) <= 1e-5 * 255
+    rs = O.make_reference_state(ref, *pkg.synth.roi_circle(n), cfg)
+    for b in (0, 11, 23, 24, 37, 47):
+        o = O.process_frame(frames[b], rs, cfg, *cal, keep_intermediates=True)
+        di = o["inter"]["demod"]["inter"]
+        assert np.array_equal(bad0[b] != 0, di["bad"])
+        assert float(np.abs(img0[b] - di["img_inpainted"]).max()) <= 1e-5 * 255
