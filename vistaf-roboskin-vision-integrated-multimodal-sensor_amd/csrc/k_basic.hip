@@ -361,6 +361,44 @@ __global__ __launch_bounds__(256) void k_gauss_cols(const float *__restrict__ sr
         if (y0 + o < h) dst[b * (size_t)h * w + (size_t)(y0 + o) * w + x] = acc[o];
 }
 
+// Column pass through LDS: the block's 64 columns x (32 + ksize - 1) source rows are staged with ONE round of independent coalesced
+// loads (the register-window kernel above walks its taps with a dependent load per row: ~ksize L2 round trips per thread), then every
+// thread slides over its 8 output rows.  Same taps in the same order as k_gauss_cols: same bits.
+__global__ __launch_bounds__(256) void k_gauss_cols_lds(const float *__restrict__ src, float *__restrict__ dst,
+                                                        const float *__restrict__ kern, int ksize, int h, int w)
+{
+    extern __shared__ float lds[];
+    float *kk = lds;                       // [GB_MAXK]
+    float *tile = lds + GB_MAXK;           // [(32 + ksize - 1)][64]
+    const int r = ksize / 2, rows = 32 + ksize - 1;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + tx;
+    const int yb = blockIdx.y * 32;
+    const size_t b = blockIdx.z;
+    const float *s = src + b * (size_t)h * w;
+    for (int i = threadIdx.x; i < ksize; i += 256) kk[i] = kern[i];
+    const int xc = x < w ? x : w - 1;
+    for (int j = ty; j < rows; j += 4) tile[j * 64 + tx] = s[(size_t)reflect101(yb + j - r, h) * w + xc];
+    __syncthreads();
+    const int y0 = yb + ty * GC_R;
+    if (x >= w || y0 >= h) return;
+    float acc[GC_R];
+#pragma unroll
+    for (int o = 0; o < GC_R; o++) acc[o] = 0.f;
+    const float *t0 = tile + (ty * GC_R) * 64 + tx;
+    for (int j = 0; j < ksize + GC_R - 1; j++) {
+        const float v = t0[j * 64];
+#pragma unroll
+        for (int o = 0; o < GC_R; o++) {
+            const int t = j - o;
+            if (t >= 0 && t < ksize) acc[o] = fmaf(kk[t], v, acc[o]);
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < GC_R; o++)
+        if (y0 + o < h) dst[b * (size_t)h * w + (size_t)(y0 + o) * w + x] = acc[o];
+}
+
 void launch_gauss_rows(const float *src, float *dst, const float *kern, int ksize, int B, int h, int w, hipStream_t st)
 {
     dim3 grid((w + GB_TX - 1) / GB_TX, (h + GB_TY - 1) / GB_TY, B);
@@ -371,6 +409,8 @@ void launch_gauss_rows(const float *src, float *dst, const float *kern, int ksiz
 void launch_gauss_cols(const float *src, float *dst, const float *kern, int ksize, int B, int h, int w, hipStream_t st)
 {
     dim3 grid((w + 63) / 64, (h + 4 * GC_R - 1) / (4 * GC_R), B);
+    const size_t lds = (GB_MAXK + (size_t)(32 + ksize - 1) * 64) * sizeof(float);
+    if (lds <= 64 * 1024) { hipLaunchKernelGGL(k_gauss_cols_lds, grid, dim3(256), lds, st, src, dst, kern, ksize, h, w); return; }
     hipLaunchKernelGGL(k_gauss_cols, grid, dim3(256), 0, st, src, dst, kern, ksize, h, w);
 }
 

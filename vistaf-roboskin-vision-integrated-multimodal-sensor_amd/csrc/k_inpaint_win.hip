@@ -35,15 +35,35 @@ __device__ unsigned long long g_win_dbg[1024][16];   // diagnostic shader-clock 
 
 
 // box planes [4][B]: xmin, ymin (start 0x7f7f7f7f), xmax, ymax (start 0) of the hole pixels of each frame
-__global__ void k_bad_bbox(const uint8_t *__restrict__ bad, int32_t *__restrict__ box, int B, int h, int w)
+// VEC: 16 mask bytes per thread (P must be a multiple of 16); most words are zero, coordinates are only formed for set bytes
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_bad_bbox(const uint8_t *__restrict__ bad, int32_t *__restrict__ box, int B, int h, int w)
 {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    int b = blockIdx.y;
-    int P = h * w;
-    bool on = p < P && bad[(size_t)b * P + p];
-    if (!__ballot(on)) return;
-    int y = p / w, x = p - y * w;
-    int x0 = on ? x : 0x7f7f7f7f, y0 = on ? y : 0x7f7f7f7f, x1 = on ? x : 0, y1 = on ? y : 0;
+    const int b = blockIdx.y;
+    const int P = h * w;
+    int x0 = 0x7f7f7f7f, y0 = 0x7f7f7f7f, x1 = 0, y1 = 0;
+    bool any = false;
+    if (VEC) {
+        const int q = blockIdx.x * blockDim.x + threadIdx.x;              // 16-byte word of the frame
+        if (q * 16 < P) {
+            const uint4 v = ((const uint4 *)(bad + (size_t)b * P))[q];
+            const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+            if (v.x | v.y | v.z | v.w) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    if ((wd[k >> 2] >> (8 * (k & 3))) & 0xffu) {
+                        const int p = q * 16 + k, y = p / w, x = p - y * w;
+                        x0 = min(x0, x); y0 = min(y0, y); x1 = max(x1, x); y1 = max(y1, y);
+                        any = true;
+                    }
+                }
+            }
+        }
+    } else {
+        const int p = blockIdx.x * blockDim.x + threadIdx.x;
+        if (p < P && bad[(size_t)b * P + p]) { y0 = y1 = p / w; x0 = x1 = p - y0 * w; any = true; }
+    }
+    if (!__ballot(any)) return;
     for (int o = 32; o; o >>= 1) {
         x0 = min(x0, __shfl_xor(x0, o, 64)); y0 = min(y0, __shfl_xor(y0, o, 64));
         x1 = max(x1, __shfl_xor(x1, o, 64)); y1 = max(y1, __shfl_xor(y1, o, 64));
@@ -306,7 +326,8 @@ int32_t *launch_inpaint_window(float *img, const uint8_t *bad, int range, void *
     (void)hipMemsetAsync(box, 0x7f, (size_t)B * 8, st);
     (void)hipMemsetAsync(box + 2 * (size_t)B, 0, (size_t)B * 12, st);
     const int P = h * w;
-    hipLaunchKernelGGL(k_bad_bbox, dim3((P + 255) / 256, B), dim3(256), 0, st, bad, box, B, h, w);
+    if (P % 16 == 0) hipLaunchKernelGGL(k_bad_bbox<true>, dim3((P / 16 + 255) / 256, B), dim3(256), 0, st, bad, box, B, h, w);
+    else hipLaunchKernelGGL(k_bad_bbox<false>, dim3((P + 255) / 256, B), dim3(256), 0, st, bad, box, B, h, w);
     const size_t lds = (size_t)WN_CELLS * 9 + (size_t)WN_QCAP * 8 + 256;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_telea_window, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }

@@ -279,60 +279,65 @@ __global__ __launch_bounds__(1024) void k_tail(const float *__restrict__ height_
     size_t b = blockIdx.x;
     const float *H = height_mm + b * (size_t)P;
     const uint8_t *R = roi_frame ? roi_frame + b * (size_t)P : nullptr;
-    // dominant sign: nansum(neg) > nansum(pos)  (float32 sums upstream; double here)
-    double sp = 0, sn = 0;
-    for (int p = threadIdx.x; p < P; p += blockDim.x) {
-        float v = H[p];
-        if (v == v) { if (v > 0.f) sp += v; else sn += -v; }
+    // ONE pass over the planes, four pixels per thread in flight: the dominant sign (nansum(neg) > nansum(pos); float32 sums upstream,
+    // double here) is only known at the end, so the volume / area / maximum are accumulated for both signs and the right set is kept.
+    // Per thread the pixels come in the same order as in separate passes: the sums are the same bits.
+    const float *U = unitless ? unitless + b * (size_t)P : nullptr;
+    const bool want_arg = scalars != nullptr;
+    const float eps = (float)pp.depth_eps_mm;
+    double sp = 0, sn = 0, volp = 0, voln = 0;
+    int cntp = 0, cntn = 0;
+    unsigned long long mxp = 0, mxn = 0, am = 0, an = ~0ull;
+    constexpr int TU = 4;
+    const int T = blockDim.x;
+    for (int p0 = threadIdx.x; p0 < P; p0 += TU * T) {
+        float v[TU], u[TU];
+        uint8_t rf[TU], rs[TU];
+#pragma unroll
+        for (int k = 0; k < TU; k++) {
+            const int p = p0 + k * T;
+            const bool inb = p < P;
+            v[k] = inb ? H[p] : nanf32();
+            rf[k] = (inb && R) ? R[p] : (uint8_t)0;
+            rs[k] = (inb && want_arg) ? roi_static[p] : (uint8_t)0;
+            u[k] = (inb && U) ? U[p] : nanf32();
+        }
+#pragma unroll
+        for (int k = 0; k < TU; k++) {
+            const int p = p0 + k * T;
+            if (p >= P) break;
+            const float vv = v[k];
+            if (vv == vv) { if (vv > 0.f) sp += vv; else sn += -vv; }
+            const bool in = R ? rf[k] != 0 : finitef(vv);
+            float dp = fmaxf(vv, 0.f), dn = fmaxf(-vv, 0.f);
+            if (!in || !finitef(dp)) dp = 0.f;
+            if (!in || !finitef(dn)) dn = 0.f;
+            if (dp > eps) { volp += dp; cntp++; const unsigned long long key = (unsigned long long)__float_as_uint(dp) << 32; if (key > mxp) mxp = key; }
+            if (dn > eps) { voln += dn; cntn++; const unsigned long long key = (unsigned long long)__float_as_uint(dn) << 32; if (key > mxn) mxn = key; }
+            if (rs[k] && finitef(vv)) {            // arg-max of depth (mm) over roi & finite: first occurrence of the maximum
+                const unsigned long long key = ((unsigned long long)f2key(vv) << 32) | (unsigned int)(0xffffffffu - (unsigned int)p);
+                if (key > am) am = key;
+            }
+            if (rs[k] && finitef(u[k])) {          // arg-min of unitless height over roi & finite: first occurrence of the minimum
+                const unsigned long long key = ((unsigned long long)f2key(u[k]) << 32) | (unsigned int)p;
+                if (key < an) an = key;
+            }
+        }
     }
     sp = block_sum<double>(sp, sd);
     sn = block_sum<double>(sn, sd);
-    bool use_neg = (float)sn > (float)sp;
-    float eps = (float)pp.depth_eps_mm;
-    double vol = 0; int cnt = 0; unsigned long long mx = 0;
-    for (int p = threadIdx.x; p < P; p += blockDim.x) {
-        float v = H[p];
-        bool in = R ? R[p] != 0 : finitef(v);
-        float d = use_neg ? fmaxf(-v, 0.f) : fmaxf(v, 0.f);
-        if (!in || !finitef(d)) d = 0.f;
-        if (d > eps) {
-            vol += d; cnt++;
-            unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32);
-            if (key > mx) mx = key;
-        }
-    }
-    vol = block_sum<double>(vol, sd);
-    double cntd = block_sum<double>((double)cnt, sd);
-    mx = block_max_u64(mx, s64);
+    const bool use_neg = (float)sn > (float)sp;
+    double vol = block_sum<double>(use_neg ? voln : volp, sd);
+    double cntd = block_sum<double>((double)(use_neg ? cntn : cntp), sd);
+    unsigned long long mx = block_max_u64(use_neg ? mxn : mxp, s64);
     double area_px = pp.mm_per_px * pp.mm_per_px;
     double volume_cm3 = cntd > 0 ? (double)(float)vol * area_px / 1000.0 : 0.0;
     double area_mm2 = cntd * area_px;
     double maxd = cntd > 0 ? (double)__uint_as_float((unsigned int)(mx >> 32)) : 0.0;
     if (out3 && threadIdx.x == 0) { out3[b * 3] = volume_cm3; out3[b * 3 + 1] = area_mm2; out3[b * 3 + 2] = maxd; }
     if (!scalars) return;
-    // arg-max of depth (mm) over roi & finite: first occurrence of the maximum
-    unsigned long long am = 0;
-    for (int p = threadIdx.x; p < P; p += blockDim.x) {
-        float v = H[p];
-        if (roi_static[p] && finitef(v)) {
-            unsigned long long key = ((unsigned long long)f2key(v) << 32) | (unsigned int)(0xffffffffu - (unsigned int)p);
-            if (key > am) am = key;
-        }
-    }
     am = block_max_u64(am, s64);
-    // arg-min of unitless height over roi & finite: first occurrence of the minimum
-    unsigned long long an = ~0ull;
-    if (unitless) {
-        const float *U = unitless + b * (size_t)P;
-        for (int p = threadIdx.x; p < P; p += blockDim.x) {
-            float v = U[p];
-            if (roi_static[p] && finitef(v)) {
-                unsigned long long key = ((unsigned long long)f2key(v) << 32) | (unsigned int)p;
-                if (key < an) an = key;
-            }
-        }
-        an = block_min_u64(an, s64);
-    }
+    if (unitless) an = block_min_u64(an, s64);
     if (threadIdx.x == 0) {
         double *S = scalars + b * (size_t)nscal;
         S[0] = volume_cm3; S[1] = area_mm2; S[2] = maxd;
