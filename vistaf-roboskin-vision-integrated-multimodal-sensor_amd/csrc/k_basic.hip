@@ -386,13 +386,18 @@ __global__ __launch_bounds__(256) void k_gauss_cols_lds(const float *__restrict_
 #pragma unroll
     for (int o = 0; o < GC_R; o++) acc[o] = 0.f;
     const float *t0 = tile + (ty * GC_R) * 64 + tx;
+    // kw[o] = kk[j - o], 0 outside the kernel: one tap read per source row instead of eight, no bounds tests.  A zero tap adds
+    // +-0 to a sum that is never -0 (it starts at +0), so the result is the bit pattern of the tested loop.
+    float kw[GC_R];
+#pragma unroll
+    for (int o = 0; o < GC_R; o++) kw[o] = 0.f;
     for (int j = 0; j < ksize + GC_R - 1; j++) {
         const float v = t0[j * 64];
 #pragma unroll
-        for (int o = 0; o < GC_R; o++) {
-            const int t = j - o;
-            if (t >= 0 && t < ksize) acc[o] = fmaf(kk[t], v, acc[o]);
-        }
+        for (int o = GC_R - 1; o > 0; o--) kw[o] = kw[o - 1];
+        kw[0] = j < ksize ? kk[j] : 0.f;
+#pragma unroll
+        for (int o = 0; o < GC_R; o++) acc[o] = fmaf(kw[o], v, acc[o]);
     }
 #pragma unroll
     for (int o = 0; o < GC_R; o++)
