@@ -324,8 +324,9 @@ __global__ __launch_bounds__(256) void k_gauss_rows(const float *__restrict__ sr
     int x = x0 + tx;
     if (y >= h || x >= w) return;
     const float *t = tile + ty * tw + tx;
-    float acc = kk[0] * t[0];
-    for (int j = 1; j < ksize; j++) acc = fmaf(kk[j], t[j], acc);
+    // taps straight from `kern`: a wave-uniform address in read-only memory is a scalar load, which keeps the LDS port for the samples
+    float acc = kern[0] * t[0];
+    for (int j = 1; j < ksize; j++) acc = fmaf(kern[j], t[j], acc);
     dst[b * (size_t)h * w + (size_t)y * w + x] = acc;
 }
 
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(256) void k_gauss_cols_lds(const float *__restrict_
         const float v = t0[j * 64];
 #pragma unroll
         for (int o = GC_R - 1; o > 0; o--) kw[o] = kw[o - 1];
-        kw[0] = j < ksize ? kk[j] : 0.f;
+        kw[0] = j < ksize ? kern[j] : 0.f;
 #pragma unroll
         for (int o = 0; o < GC_R; o++) acc[o] = fmaf(kw[o], v, acc[o]);
     }
