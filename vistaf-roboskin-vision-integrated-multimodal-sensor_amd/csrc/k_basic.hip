@@ -170,7 +170,8 @@ __global__ void k_morph_prefix(const uint16_t *__restrict__ inc, uint8_t *__rest
 // packs the mask into 64-bit words with ballots (coalesced byte loads), dilates in LDS with word shifts -- a
 // 15x15 element costs a few hundred 64-bit ops per output word -- and unpacks.  Erosion is the dual: complement inside
 // the image, dilate, complement (out-of-image pixels never erode: cv::morphologyDefaultBorderValue).
-constexpr int MB_T = 256;
+constexpr int MB_T = 1024;      // 16 waves: packing / unpacking a row is a global-memory round trip, so rows in flight are what counts
+constexpr int MB_RB = 2;        // rows per wave and iteration (MB_RB * 4 independent byte loads in flight per lane)
 constexpr int MB_MAXOPS = 4;
 struct MorphSeq {               // up to MB_MAXOPS operations applied back to back on the packed plane (close = dilate, erode; n-fold dilate)
     int n;
@@ -186,17 +187,24 @@ __global__ __launch_bounds__(MB_T) void k_morph_bits(const uint8_t *__restrict__
     const size_t b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint8_t *s = src + b * (size_t)h * w;
-    // pack: the byte loads of a row are independent and issued together
-    for (int y = wid; y < h; y += MB_T / 64)
+    // pack: the byte loads of MB_RB rows are independent and issued together
+    for (int y0 = wid * MB_RB; y0 < h; y0 += (MB_T / 64) * MB_RB)
         for (int j0 = 0; j0 < W64; j0 += 4) {
-            uint8_t px[4];
+            uint8_t px[MB_RB][4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const int x = (j0 + u) * 64 + lane; px[u] = (j0 + u < W64 && x < w) ? s[(size_t)y * w + x] : (uint8_t)0; }
+            for (int rr = 0; rr < MB_RB; rr++)
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const unsigned long long word = __ballot(px[u] != 0);
-                if (lane == 0 && j0 + u < W64) A[y * W64 + j0 + u] = word;
-            }
+                for (int u = 0; u < 4; u++) {
+                    const int y = y0 + rr, x = (j0 + u) * 64 + lane;
+                    px[rr][u] = (y < h && j0 + u < W64 && x < w) ? s[(size_t)y * w + x] : (uint8_t)0;
+                }
+#pragma unroll
+            for (int rr = 0; rr < MB_RB; rr++)
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const unsigned long long word = __ballot(px[rr][u] != 0);
+                    if (lane == 0 && y0 + rr < h && j0 + u < W64) A[(y0 + rr) * W64 + j0 + u] = word;
+                }
         }
     __syncthreads();
     const unsigned long long last_valid = (w & 63) ? ((1ull << (w & 63)) - 1ull) : ~0ull;     // columns of the last word that exist
@@ -228,23 +236,27 @@ __global__ __launch_bounds__(MB_T) void k_morph_bits(const uint8_t *__restrict__
     }
     // unpack (A holds the result); the optional AND masks of a row are loaded together
     uint8_t *o = dst + b * (size_t)h * w;
-    for (int y = wid; y < h; y += MB_T / 64)
+    for (int y0 = wid * MB_RB; y0 < h; y0 += (MB_T / 64) * MB_RB)
         for (int j0 = 0; j0 < W64; j0 += 4) {
-            uint8_t ms[4], mf[4];
+            uint8_t ms[MB_RB][4], mf[MB_RB][4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int x = (j0 + u) * 64 + lane;
-                const size_t p = (j0 + u < W64 && x < w) ? (size_t)y * w + x : 0;
-                ms[u] = and_static ? and_static[p] : (uint8_t)1;
-                mf[u] = and_frame ? and_frame[b * (size_t)h * w + p] : (uint8_t)1;
-            }
+            for (int rr = 0; rr < MB_RB; rr++)
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int x = (j0 + u) * 64 + lane;
-                if (j0 + u >= W64 || x >= w) continue;
-                const int v = (int)((A[y * W64 + j0 + u] >> lane) & 1ull);
-                o[(size_t)y * w + x] = (uint8_t)(v && ms[u] && mf[u]);
-            }
+                for (int u = 0; u < 4; u++) {
+                    const int y = y0 + rr, x = (j0 + u) * 64 + lane;
+                    const size_t p = (y < h && j0 + u < W64 && x < w) ? (size_t)y * w + x : 0;
+                    ms[rr][u] = and_static ? and_static[p] : (uint8_t)1;
+                    mf[rr][u] = and_frame ? and_frame[b * (size_t)h * w + p] : (uint8_t)1;
+                }
+#pragma unroll
+            for (int rr = 0; rr < MB_RB; rr++)
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int y = y0 + rr, x = (j0 + u) * 64 + lane;
+                    if (y >= h || j0 + u >= W64 || x >= w) continue;
+                    const int v = (int)((A[y * W64 + j0 + u] >> lane) & 1ull);
+                    o[(size_t)y * w + x] = (uint8_t)(v && ms[rr][u] && mf[rr][u]);
+                }
         }
 }
 
