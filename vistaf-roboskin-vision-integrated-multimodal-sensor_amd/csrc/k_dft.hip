@@ -86,32 +86,51 @@ __global__ void k_dft_inv1(const float2 *__restrict__ patch, const float2 *__res
     Q[(b * (size_t)ph + a) * w + x] = make_double2(ar, ai);
 }
 
-// stage 4: field[b, y, x] = sum_a Gy[y, a] * Q[b, a, x];  amp = |field|
-__global__ void k_dft_inv2(const double2 *__restrict__ Q, const float2 *__restrict__ Gy, float2 *__restrict__ field,
-                           float *__restrict__ amp, int h, int w, int ph)
+// stage 4: field[b, y, x] = sum_a Gy[y, a] * Q[b, a, x];  amp = |field|.  A thread produces DFT_RY rows of one column: every Q word it
+// loads feeds DFT_RY outputs (one output per thread re-read the frame's Q once per row through the L2: the kernel ran at L2 bandwidth).
+// The Gy rows of the block sit in LDS; the sums run over a in the same order as before: same bits.
+constexpr int DFT_RY = 8;
+__global__ __launch_bounds__(256) void k_dft_inv2(const double2 *__restrict__ Q, const float2 *__restrict__ Gy, float2 *__restrict__ field,
+                                                  float *__restrict__ amp, int h, int w, int ph)
 {
-    int x = blockIdx.x * blockDim.x + threadIdx.x;
-    int y = blockIdx.y;
-    size_t b = blockIdx.z;
+    extern __shared__ float2 gy_lds[];                  // [DFT_RY][ph]
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y0 = blockIdx.y * DFT_RY;
+    const size_t b = blockIdx.z;
+    for (int i = threadIdx.x; i < DFT_RY * ph; i += blockDim.x) {
+        const int r = i / ph, a = i - r * ph;
+        gy_lds[i] = y0 + r < h ? Gy[(size_t)(y0 + r) * ph + a] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
     if (x >= w) return;
     const double2 *Qb = Q + b * (size_t)ph * w;
-    double ar = 0.0, ai = 0.0;
+    double ar[DFT_RY], ai[DFT_RY];
+#pragma unroll
+    for (int r = 0; r < DFT_RY; r++) { ar[r] = 0.0; ai[r] = 0.0; }
     for (int a = 0; a < ph; a++) {
-        float2 g = Gy[(size_t)y * ph + a];
-        double2 q = Qb[(size_t)a * w + x];
-        ar += (double)g.x * q.x - (double)g.y * q.y;
-        ai += (double)g.x * q.y + (double)g.y * q.x;
+        const double2 q = Qb[(size_t)a * w + x];
+#pragma unroll
+        for (int r = 0; r < DFT_RY; r++) {
+            const float2 g = gy_lds[r * ph + a];
+            ar[r] += (double)g.x * q.x - (double)g.y * q.y;
+            ai[r] += (double)g.x * q.y + (double)g.y * q.x;
+        }
     }
-    size_t i = b * (size_t)h * w + (size_t)y * w + x;
-    field[i] = make_float2((float)ar, (float)ai);
-    amp[i] = (float)sqrt(ar * ar + ai * ai);
+#pragma unroll
+    for (int r = 0; r < DFT_RY; r++) {
+        if (y0 + r >= h) break;
+        const size_t i = b * (size_t)h * w + (size_t)(y0 + r) * w + x;
+        field[i] = make_float2((float)ar[r], (float)ai[r]);
+        amp[i] = (float)sqrt(ar[r] * ar[r] + ai[r] * ai[r]);
+    }
 }
 
 void launch_dft_inverse(const float2 *patch, const float2 *Gx, const float2 *Gy, float2 *tmpQ, float2 *field, float *amp,
                         int B, int h, int w, int ph, int pw, hipStream_t st)
 {
     hipLaunchKernelGGL(k_dft_inv1, dim3((w + 255) / 256, ph, B), dim3(256), 0, st, patch, Gx, (double2 *)tmpQ, w, ph, pw);
-    hipLaunchKernelGGL(k_dft_inv2, dim3((w + 255) / 256, h, B), dim3(256), 0, st, (const double2 *)tmpQ, Gy, field, amp, h, w, ph);
+    hipLaunchKernelGGL(k_dft_inv2, dim3((w + 255) / 256, (h + DFT_RY - 1) / DFT_RY, B), dim3(256), (size_t)DFT_RY * ph * sizeof(float2), st,
+                       (const double2 *)tmpQ, Gy, field, amp, h, w, ph);
 }
 
 // ---- full spectrum magnitude of ONE frame (reference-frame carrier search, shape_ftp.py:867-872) ----
