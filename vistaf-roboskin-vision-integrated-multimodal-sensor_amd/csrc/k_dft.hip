@@ -10,31 +10,40 @@
 
 namespace vf {
 
-constexpr int DFT_RB = 12;   // rows per workgroup in stage 1 (12 * 21 = 252 threads)
+constexpr int DFT_RB = 12;   // row groups per workgroup in stage 1 (12 * 21 = 252 threads)
+constexpr int DFT_RR = 4;    // rows per thread in stage 1: every twiddle loaded feeds DFT_RR rows
 
-// stage 1: T[b, y, c] = sum_x (iw[b,y,x] - mu[b]) * Ex[x, c]
+// stage 1: T[b, y, c] = sum_x (iw[b,y,x] - mu[b]) * Ex[x, c].  Thread = (row group, c); the rows of the block are staged in LDS.
 __global__ __launch_bounds__(256) void k_dft_fwd1(const float *__restrict__ iw, const float *__restrict__ mu,
                                                   const float2 *__restrict__ Ex, double2 *__restrict__ T, int h, int w, int pw, int rb)
 {
-    extern __shared__ float rows[];   // rb * w
+    extern __shared__ float rows[];   // rb * DFT_RR * w
     size_t b = blockIdx.y;
-    int y0 = blockIdx.x * rb;
-    int nr = min(rb, h - y0);
+    int y0 = blockIdx.x * rb * DFT_RR;
+    int nr = min(rb * DFT_RR, h - y0);
     const float *src = iw + b * (size_t)h * w + (size_t)y0 * w;
     float m = mu ? mu[b] : 0.f;
     for (int i = threadIdx.x; i < nr * w; i += blockDim.x) rows[i] = __fsub_rn(src[i], m);
+    for (int i = nr * w + threadIdx.x; i < rb * DFT_RR * w; i += blockDim.x) rows[i] = 0.f;
     __syncthreads();
-    int ry = threadIdx.x / pw, c = threadIdx.x % pw;
-    if (ry >= nr) return;
-    const float *r = rows + ry * w;
-    double ar = 0.0, ai = 0.0;
+    int rg = threadIdx.x / pw, c = threadIdx.x % pw;
+    if (rg >= rb || rg * DFT_RR >= nr) return;
+    const float *r = rows + rg * DFT_RR * w;
+    double ar[DFT_RR], ai[DFT_RR];
+#pragma unroll
+    for (int k = 0; k < DFT_RR; k++) { ar[k] = 0.0; ai[k] = 0.0; }
     for (int x = 0; x < w; x++) {
-        float2 e = Ex[(size_t)x * pw + c];
-        double v = r[x];
-        ar = fma(v, (double)e.x, ar);
-        ai = fma(v, (double)e.y, ai);
+        const float2 e = Ex[(size_t)x * pw + c];
+#pragma unroll
+        for (int k = 0; k < DFT_RR; k++) {
+            const double v = r[k * w + x];
+            ar[k] = fma(v, (double)e.x, ar[k]);
+            ai[k] = fma(v, (double)e.y, ai[k]);
+        }
     }
-    T[(b * (size_t)h + y0 + ry) * pw + c] = make_double2(ar, ai);
+#pragma unroll
+    for (int k = 0; k < DFT_RR; k++)
+        if (rg * DFT_RR + k < nr) T[(b * (size_t)h + y0 + rg * DFT_RR + k) * pw + c] = make_double2(ar[k], ai[k]);
 }
 
 // stage 2: patch[b, a, c] = win[a,c] * sum_y Ey[a, y] * T[b, y, c]
@@ -63,9 +72,11 @@ void launch_dft_forward(const float *iw, const float *mu, const float2 *Ex, cons
 {
     int rb = 256 / pw;
     if (rb > DFT_RB) rb = DFT_RB;
+    const int rb_lds = (int)((60 * 1024) / ((size_t)DFT_RR * w * sizeof(float)));     // staged rows must fit the default dynamic LDS limit
+    if (rb > rb_lds) rb = rb_lds;
     if (rb < 1) rb = 1;
-    dim3 g1((h + rb - 1) / rb, B);
-    hipLaunchKernelGGL(k_dft_fwd1, g1, dim3(256), (size_t)rb * w * sizeof(float), st, iw, mu, Ex, (double2 *)tmpT, h, w, pw, rb);
+    dim3 g1((h + rb * DFT_RR - 1) / (rb * DFT_RR), B);
+    hipLaunchKernelGGL(k_dft_fwd1, g1, dim3(256), (size_t)rb * DFT_RR * w * sizeof(float), st, iw, mu, Ex, (double2 *)tmpT, h, w, pw, rb);
     hipLaunchKernelGGL(k_dft_fwd2, dim3(B), dim3(((ph * pw + 63) / 64) * 64), 0, st, (const double2 *)tmpT, Ey, win, patch, h, ph, pw);
 }
 
