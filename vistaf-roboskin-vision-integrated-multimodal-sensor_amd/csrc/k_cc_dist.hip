@@ -7,6 +7,7 @@
 //
 // One 1024-thread workgroup owns one frame, so every union-find word is only touched by one CU; loads
 // of label words go through agent-scope relaxed atomics (served by L2, never a stale L1 line).
+#include <cstdlib>
 #include "kernels.hpp"
 
 namespace vf {
@@ -445,16 +446,99 @@ __global__ __launch_bounds__(64) void k_chamfer2(const uint8_t *__restrict__ src
     }
 }
 
+// ---- the same distances from the closed form, one 1024-thread workgroup per frame, exact up to `cap` rows (all the callers look at).
+// The chamfer metric between two pixels is HV * (max - min) + DG * min of (|dx|, |dy|), and it grows with |dx| for a fixed |dy|, so
+//   d(x, y) = min over rows y' of metric(g(y', x), |y - y'|),   g = horizontal distance to the nearest zero pixel of row y'.
+// Phase 1 (rows are independent: 16 waves, a DPP max / min scan per 64-pixel chunk) leaves g in LDS as uint16; phase 2 is a short
+// loop per pixel with the early exit of k_chamfer_cols.  The two-pass kernel above is one wave per frame and 2 * h dependent row steps.
+constexpr uint16_t CHL_NONE = 0xffffu;
+__device__ inline int chl_scan_max(int v)      // inclusive prefix maximum over lanes 0..l
+{
+    int t;
+    t = __builtin_amdgcn_update_dpp((int)0x80000000, v, 0x111, 0xf, 0xf, false); v = t > v ? t : v;
+    t = __builtin_amdgcn_update_dpp((int)0x80000000, v, 0x112, 0xf, 0xf, false); v = t > v ? t : v;
+    t = __builtin_amdgcn_update_dpp((int)0x80000000, v, 0x114, 0xf, 0xf, false); v = t > v ? t : v;
+    t = __builtin_amdgcn_update_dpp((int)0x80000000, v, 0x118, 0xf, 0xf, false); v = t > v ? t : v;
+    t = __builtin_amdgcn_update_dpp((int)0x80000000, v, 0x142, 0xa, 0xf, false); v = t > v ? t : v;
+    t = __builtin_amdgcn_update_dpp((int)0x80000000, v, 0x143, 0xc, 0xf, false); v = t > v ? t : v;
+    return v;
+}
+__global__ __launch_bounds__(1024) void k_chamfer_lds(const uint8_t *__restrict__ src_all, int invert, float *__restrict__ dist_all, int h, int w,
+                                                      int cap)
+{
+    extern __shared__ uint16_t chl_g[];                  // [h * w]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const size_t b = blockIdx.x;
+    const int P = h * w;
+    const uint8_t *src = src_all + b * (size_t)P;
+    // phase 1: last zero at or left of x (prefix max of positions), first zero at or right of x (prefix max over the mirrored row)
+    for (int y = wid; y < h; y += 16) {
+        const uint8_t *row = src + (size_t)y * w;
+        int carry = -0x40000000;                          // position of the last zero seen in earlier chunks (none)
+        for (int x0 = 0; x0 < w; x0 += 64) {
+            const int x = x0 + lane;
+            const bool zero = x < w && (invert ? row[x] != 0 : row[x] == 0);
+            int lz = chl_scan_max(zero ? x : -0x40000000);
+            lz = lz > carry ? lz : carry;
+            carry = __builtin_amdgcn_readlane(lz, 63);
+            if (x < w) { const int d = x - lz; chl_g[y * w + x] = d > 0xfffe ? CHL_NONE : (uint16_t)d; }
+        }
+        carry = -0x40000000;                              // mirrored: position counted from the right end
+        for (int x0 = 0; x0 < w; x0 += 64) {
+            const int xm = x0 + lane, x = w - 1 - xm;     // xm = mirrored position
+            const bool zero = xm < w && (invert ? row[x] != 0 : row[x] == 0);
+            int lz = chl_scan_max(zero ? xm : -0x40000000);
+            lz = lz > carry ? lz : carry;
+            carry = __builtin_amdgcn_readlane(lz, 63);
+            if (xm < w) {
+                const int d = xm - lz;
+                const uint16_t dr = d > 0xfffe ? CHL_NONE : (uint16_t)d, dl = chl_g[y * w + x];
+                chl_g[y * w + x] = dr < dl ? dr : dl;
+            }
+        }
+    }
+    __syncthreads();
+    // phase 2
+    float *dist = dist_all + b * (size_t)P;
+    for (int p = tid; p < P; p += 1024) {
+        const int y = p / w, x = p - y * w;
+        int best = CH_DIST_MAX;
+        for (int dy = 0; dy <= cap; dy++) {
+            if ((long long)dy * CH_HV >= best) break;
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                if (s && !dy) break;
+                const int yy = s ? y + dy : y - dy;
+                if (yy < 0 || yy >= h) continue;
+                const int gx = (int)chl_g[yy * w + x];
+                if (gx == (int)CHL_NONE) continue;
+                const int mn = gx < dy ? gx : dy, mx = gx < dy ? dy : gx;
+                const int c = CH_HV * (mx - mn) + CH_DG * mn;
+                if (c < best) best = c;
+            }
+        }
+        dist[p] = (float)best * (1.0f / 65536.0f);
+    }
+}
+
 void launch_chamfer(const uint8_t *src, bool invert, int32_t *rowdist, float *dist, int B, int h, int w, int cap_px, hipStream_t st)
 {
+    // small caps (the erosion margins): a handful of rows per pixel on 16 waves; for wide bands the per-pixel loop costs more than
+    // the one-wave two-pass kernel (measured at cap 46: 345 us against 200 us)
+    int cap = (int)((cap_px + 2) / 0.955) + 2;
+    if (cap > h) cap = h;
+    if (!getenv("VISTAF_CHAMFER_TWOPASS") && cap <= 16 && (size_t)h * w * 2 <= 150 * 1024 && w < 0xfffe) {
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_chamfer_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        hipLaunchKernelGGL(k_chamfer_lds, dim3(B), dim3(1024), (size_t)h * w * 2, st, src, invert ? 1 : 0, dist, h, w, cap);
+        return;
+    }
     (void)cap_px;
     if (w <= 256) { hipLaunchKernelGGL(k_chamfer2<4>, dim3(B), dim3(64), 0, st, src, invert ? 1 : 0, rowdist, dist, h, w); return; }
     if (w <= 512) { hipLaunchKernelGGL(k_chamfer2<8>, dim3(B), dim3(64), 0, st, src, invert ? 1 : 0, rowdist, dist, h, w); return; }
     // wider frames: closed form of the same two passes, exact up to cap_px (all that the callers look at)
     int rows = B * h;
     hipLaunchKernelGGL(k_rowdist, dim3((rows + 63) / 64), dim3(64), 0, st, src, invert ? 1 : 0, rowdist, h, w, B);
-    int cap = (int)((cap_px + 2) / 0.955) + 2;
-    if (cap > h) cap = h;
     hipLaunchKernelGGL(k_chamfer_cols, dim3((w + 255) / 256, h, B), dim3(256), 0, st, rowdist, dist, h, w, cap);
 }
 
