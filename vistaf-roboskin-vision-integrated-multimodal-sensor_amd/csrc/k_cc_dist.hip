@@ -135,27 +135,42 @@ __global__ __launch_bounds__(1024) void k_cc_label_lds(const uint8_t *__restrict
         __syncthreads();
     }
     const uint8_t *m = MLDS ? (const uint8_t *)ml : mg;
-    for (int p = threadIdx.x; p < P; p += blockDim.x) {
-        // start each pixel at the left end of a short horizontal run segment (cuts find chains)
-        uint16_t l = 0xffffu;
-        if (m[p]) {
-            int x = p % w, q = p;
-            for (int s = 0; s < 7 && x - s > 0 && m[q - 1]; s++) q--;
-            l = (uint16_t)q;
+    // Every pixel starts at the left end of its horizontal run (a prefix-max scan of the positions of the zero pixels of the row: 16
+    // waves, one row at a time each), so a run is one tree from the start and only the contacts between runs of adjacent rows are left
+    // to unite -- a few hundred unions per frame instead of four per pixel.  Roots are minimum pixel indices either way: same labels.
+    {
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+        for (int y = wid; y < h; y += nwv) {
+            int carry = -1;                                     // position of the last zero pixel seen in the row
+            for (int x0 = 0; x0 < w; x0 += 64) {
+                const int x = x0 + lane;
+                const bool on = x < w && m[y * w + x];
+                int lz = (x < w && !on) ? x : (int)0x80000000;
+                int t;
+                t = __builtin_amdgcn_update_dpp((int)0x80000000, lz, 0x111, 0xf, 0xf, false); lz = t > lz ? t : lz;
+                t = __builtin_amdgcn_update_dpp((int)0x80000000, lz, 0x112, 0xf, 0xf, false); lz = t > lz ? t : lz;
+                t = __builtin_amdgcn_update_dpp((int)0x80000000, lz, 0x114, 0xf, 0xf, false); lz = t > lz ? t : lz;
+                t = __builtin_amdgcn_update_dpp((int)0x80000000, lz, 0x118, 0xf, 0xf, false); lz = t > lz ? t : lz;
+                t = __builtin_amdgcn_update_dpp((int)0x80000000, lz, 0x142, 0xa, 0xf, false); lz = t > lz ? t : lz;
+                t = __builtin_amdgcn_update_dpp((int)0x80000000, lz, 0x143, 0xc, 0xf, false); lz = t > lz ? t : lz;
+                lz = lz > carry ? lz : carry;
+                carry = __builtin_amdgcn_readlane(lz, 63);
+                if (x < w) L16[y * w + x] = on ? (uint16_t)(y * w + lz + 1) : (uint16_t)0xffffu;
+            }
         }
-        L16[p] = l;
     }
     if ((P & 1) && threadIdx.x == 0) L16[P] = 0xffffu;
     __syncthreads();
     for (int p = threadIdx.x; p < P; p += blockDim.x) {
         if (!m[p]) continue;
-        int y = p / w, x = p - y * w;
-        if (x > 0 && m[p - 1]) cc16_unite(L16, p, p - 1);
-        if (y > 0) {
-            if (m[p - w]) cc16_unite(L16, p, p - w);
-            if (x > 0 && m[p - w - 1]) cc16_unite(L16, p, p - w - 1);
-            if (x < w - 1 && m[p - w + 1]) cc16_unite(L16, p, p - w + 1);
-        }
+        const int y = p / w, x = p - y * w;
+        if (y == 0) continue;
+        const bool left = x > 0 && m[p - 1];
+        const bool ul = x > 0 && m[p - w - 1], up = m[p - w] != 0, ur = x < w - 1 && m[p - w + 1];
+        // the run above-left / above: already united through the left neighbour when that one touches it too
+        if ((ul || up) && !left) cc16_unite(L16, p, ul ? p - w - 1 : p - w);
+        // a run that starts above-right
+        if (ur && !up) cc16_unite(L16, p, p - w + 1);
     }
     __syncthreads();
     int32_t *out = labels + b * (size_t)P;
