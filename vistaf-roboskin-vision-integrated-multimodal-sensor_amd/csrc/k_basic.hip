@@ -313,33 +313,49 @@ void launch_morph_seq(const uint8_t *src, uint8_t *dst, uint8_t *tmp, int B, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// Separable Gaussian, BORDER_REFLECT_101.  Row pass: 64-column x 4-row tile staged in LDS with halo.
-constexpr int GB_TX = 64, GB_TY = 4, GB_MAXK = 512;
+// Separable Gaussian, BORDER_REFLECT_101.  Row pass: 64-column x 16-row tile staged in LDS with halo.
+constexpr int GB_TX = 64, GB_TY = 16, GB_MAXK = 512;
 
 __global__ __launch_bounds__(256) void k_gauss_rows(const float *__restrict__ src, float *__restrict__ dst,
                                                     const float *__restrict__ kern, int ksize, int h, int w)
 {
+    // 64 columns x GB_TY rows per workgroup; a thread produces the same column of GB_TY / 4 rows, so a tap fetched once (a scalar
+    // load: wave-uniform address in read-only memory) feeds that many outputs and the row loads of the tile are all in flight together
     extern __shared__ float lds[];
-    int r = ksize / 2;
-    int tw = GB_TX + 2 * r;
-    float *kk = lds;                    // ksize taps
-    float *tile = lds + GB_MAXK;        // GB_TY rows of tw
-    int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    int x0 = blockIdx.x * GB_TX, y = blockIdx.y * GB_TY + ty;
-    size_t b = blockIdx.z;
-    for (int i = threadIdx.x; i < ksize; i += 256) kk[i] = kern[i];
-    if (y < h) {
-        const float *row = src + b * (size_t)h * w + (size_t)y * w;
-        for (int i = tx; i < tw; i += 64) tile[ty * tw + i] = row[reflect101(x0 + i - r, w)];
+    constexpr int NR = GB_TY / 4;
+    const int r = ksize / 2;
+    const int tw = GB_TX + 2 * r;
+    float *tile = lds;                  // GB_TY rows of tw
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int x0 = blockIdx.x * GB_TX, y0 = blockIdx.y * GB_TY;
+    const size_t b = blockIdx.z;
+    const float *plane = src + b * (size_t)h * w;
+    for (int rr = ty; rr < GB_TY; rr += 4) {
+        const int y = y0 + rr;
+        if (y >= h) break;
+        const float *row = plane + (size_t)y * w;
+        for (int i = tx; i < tw; i += 64) tile[rr * tw + i] = row[reflect101(x0 + i - r, w)];
     }
     __syncthreads();
-    int x = x0 + tx;
-    if (y >= h || x >= w) return;
+    const int x = x0 + tx;
+    if (x >= w) return;
+    float acc[NR];
     const float *t = tile + ty * tw + tx;
-    // taps straight from `kern`: a wave-uniform address in read-only memory is a scalar load, which keeps the LDS port for the samples
-    float acc = kern[0] * t[0];
-    for (int j = 1; j < ksize; j++) acc = fmaf(kern[j], t[j], acc);
-    dst[b * (size_t)h * w + (size_t)y * w + x] = acc;
+    {
+        const float k0 = kern[0];
+#pragma unroll
+        for (int q = 0; q < NR; q++) acc[q] = k0 * t[q * 4 * tw];
+    }
+    for (int j = 1; j < ksize; j++) {
+        const float kj = kern[j];
+#pragma unroll
+        for (int q = 0; q < NR; q++) acc[q] = fmaf(kj, t[q * 4 * tw + j], acc[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+        const int y = y0 + ty + 4 * q;
+        if (y < h) dst[b * (size_t)h * w + (size_t)y * w + x] = acc[q];
+    }
 }
 
 // Column pass: each thread produces GC_R consecutive rows of one column (sliding window in registers),
@@ -420,7 +436,7 @@ __global__ __launch_bounds__(256) void k_gauss_cols_lds(const float *__restrict_
 void launch_gauss_rows(const float *src, float *dst, const float *kern, int ksize, int B, int h, int w, hipStream_t st)
 {
     dim3 grid((w + GB_TX - 1) / GB_TX, (h + GB_TY - 1) / GB_TY, B);
-    size_t lds = (GB_MAXK + (size_t)GB_TY * (GB_TX + 2 * (ksize / 2))) * sizeof(float);
+    size_t lds = (size_t)GB_TY * (GB_TX + 2 * (ksize / 2)) * sizeof(float);
     hipLaunchKernelGGL(k_gauss_rows, grid, dim3(256), lds, st, src, dst, kern, ksize, h, w);
 }
 

@@ -467,17 +467,6 @@ __global__ __launch_bounds__(64) void k_chamfer2(const uint8_t *__restrict__ src
 // Phase 1 (rows are independent: 16 waves, a DPP max / min scan per 64-pixel chunk) leaves g in LDS as uint16; phase 2 is a short
 // loop per pixel with the early exit of k_chamfer_cols.  The two-pass kernel above is one wave per frame and 2 * h dependent row steps.
 constexpr uint16_t CHL_NONE = 0xffffu;
-__device__ inline int chl_scan_max(int v)      // inclusive prefix maximum over lanes 0..l
-{
-    int t;
-    t = __builtin_amdgcn_update_dpp((int)0x80000000, v, 0x111, 0xf, 0xf, false); v = t > v ? t : v;
-    t = __builtin_amdgcn_update_dpp((int)0x80000000, v, 0x112, 0xf, 0xf, false); v = t > v ? t : v;
-    t = __builtin_amdgcn_update_dpp((int)0x80000000, v, 0x114, 0xf, 0xf, false); v = t > v ? t : v;
-    t = __builtin_amdgcn_update_dpp((int)0x80000000, v, 0x118, 0xf, 0xf, false); v = t > v ? t : v;
-    t = __builtin_amdgcn_update_dpp((int)0x80000000, v, 0x142, 0xa, 0xf, false); v = t > v ? t : v;
-    t = __builtin_amdgcn_update_dpp((int)0x80000000, v, 0x143, 0xc, 0xf, false); v = t > v ? t : v;
-    return v;
-}
 __global__ __launch_bounds__(1024) void k_chamfer_lds(const uint8_t *__restrict__ src_all, int invert, float *__restrict__ dist_all, int h, int w,
                                                       int cap)
 {
@@ -486,30 +475,52 @@ __global__ __launch_bounds__(1024) void k_chamfer_lds(const uint8_t *__restrict_
     const size_t b = blockIdx.x;
     const int P = h * w;
     const uint8_t *src = src_all + b * (size_t)P;
-    // phase 1: last zero at or left of x (prefix max of positions), first zero at or right of x (prefix max over the mirrored row)
+    // phase 1: the zero pixels of a row as ballot words (the byte loads of the row are issued together: one memory round trip per
+    // row); the distances to the nearest zero at or left / right of a pixel are then bit scans of those words
+    constexpr int CHL_W = 8;                              // 64-pixel words per row handled in registers (w <= 512)
+    const int nwords = (w + 63) >> 6;
     for (int y = wid; y < h; y += 16) {
         const uint8_t *row = src + (size_t)y * w;
-        int carry = -0x40000000;                          // position of the last zero seen in earlier chunks (none)
-        for (int x0 = 0; x0 < w; x0 += 64) {
-            const int x = x0 + lane;
-            const bool zero = x < w && (invert ? row[x] != 0 : row[x] == 0);
-            int lz = chl_scan_max(zero ? x : -0x40000000);
-            lz = lz > carry ? lz : carry;
-            carry = __builtin_amdgcn_readlane(lz, 63);
-            if (x < w) { const int d = x - lz; chl_g[y * w + x] = d > 0xfffe ? CHL_NONE : (uint16_t)d; }
+        uint8_t px[CHL_W];
+#pragma unroll
+        for (int c = 0; c < CHL_W; c++) { const int x = c * 64 + lane; px[c] = (c < nwords && x < w) ? row[x] : (uint8_t)(invert ? 0 : 1); }
+        unsigned long long Z[CHL_W];
+#pragma unroll
+        for (int c = 0; c < CHL_W; c++) {
+            const int x = c * 64 + lane;
+            Z[c] = __ballot(c < nwords && x < w && (invert ? px[c] != 0 : px[c] == 0));
         }
-        carry = -0x40000000;                              // mirrored: position counted from the right end
-        for (int x0 = 0; x0 < w; x0 += 64) {
-            const int xm = x0 + lane, x = w - 1 - xm;     // xm = mirrored position
-            const bool zero = xm < w && (invert ? row[x] != 0 : row[x] == 0);
-            int lz = chl_scan_max(zero ? xm : -0x40000000);
-            lz = lz > carry ? lz : carry;
-            carry = __builtin_amdgcn_readlane(lz, 63);
-            if (xm < w) {
-                const int d = xm - lz;
-                const uint16_t dr = d > 0xfffe ? CHL_NONE : (uint16_t)d, dl = chl_g[y * w + x];
-                chl_g[y * w + x] = dr < dl ? dr : dl;
+#pragma unroll
+        for (int c = 0; c < CHL_W; c++) {
+            if (c >= nwords) break;
+            const int x = c * 64 + lane;
+            // nearest zero at or left of x
+            int dl = 0x7fff0000;
+            {
+                const unsigned long long zl = Z[c] & ((2ull << lane) - 1ull);
+                if (zl) dl = lane - (63 - __clzll((long long)zl));
+                else {
+#pragma unroll
+                    for (int k = 1; k < CHL_W; k++) {
+                        if (c - k < 0) break;
+                        if (Z[c - k]) { dl = lane + 64 * k - (63 - __clzll((long long)Z[c - k])); break; }
+                    }
+                }
             }
+            int dr = 0x7fff0000;
+            {
+                const unsigned long long zr = Z[c] >> lane;
+                if (zr) dr = __ffsll((long long)zr) - 1;
+                else {
+#pragma unroll
+                    for (int k = 1; k < CHL_W; k++) {
+                        if (c + k >= nwords) break;
+                        if (Z[c + k]) { dr = 64 * k - lane + (__ffsll((long long)Z[c + k]) - 1); break; }
+                    }
+                }
+            }
+            const int d = dl < dr ? dl : dr;
+            if (x < w) chl_g[y * w + x] = d > 0xfffe ? CHL_NONE : (uint16_t)d;
         }
     }
     __syncthreads();
@@ -542,7 +553,7 @@ void launch_chamfer(const uint8_t *src, bool invert, int32_t *rowdist, float *di
     // the one-wave two-pass kernel (measured at cap 46: 345 us against 200 us)
     int cap = (int)((cap_px + 2) / 0.955) + 2;
     if (cap > h) cap = h;
-    if (!getenv("VISTAF_CHAMFER_TWOPASS") && cap <= 16 && (size_t)h * w * 2 <= 150 * 1024 && w < 0xfffe) {
+    if (!getenv("VISTAF_CHAMFER_TWOPASS") && cap <= 16 && (size_t)h * w * 2 <= 150 * 1024 && w <= 512) {
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_chamfer_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
         hipLaunchKernelGGL(k_chamfer_lds, dim3(B), dim3(1024), (size_t)h * w * 2, st, src, invert ? 1 : 0, dist, h, w, cap);

@@ -56,7 +56,20 @@ __global__ void k_dft_fwd2(const double2 *__restrict__ T, const float2 *__restri
     int a = t / pw, c = t % pw;
     const double2 *Tb = T + b * (size_t)h * pw;
     double ar = 0.0, ai = 0.0;
-    for (int y = 0; y < h; y++) {
+    // one workgroup per frame: the loads of eight rows are issued together (the loop was one memory round trip per row)
+    int y = 0;
+    for (; y + 8 <= h; y += 8) {
+        float2 e[8];
+        double2 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { e[k] = Ey[(size_t)a * h + y + k]; v[k] = Tb[(size_t)(y + k) * pw + c]; }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            ar += (double)e[k].x * v[k].x - (double)e[k].y * v[k].y;
+            ai += (double)e[k].x * v[k].y + (double)e[k].y * v[k].x;
+        }
+    }
+    for (; y < h; y++) {
         float2 e = Ey[(size_t)a * h + y];
         double2 v = Tb[(size_t)y * pw + c];
         ar += (double)e.x * v.x - (double)e.y * v.y;
