@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_batch(const uint16_t *__res
 // its children, so walking the pop records front to back resolves everything in one sweep.  The counts live in
 // LDS (int16 per padded pixel, RP_UNSET = not yet known); each wave takes every RP_NW-th chunk of 64 records,
 // prefetches its phase values and spins on the parents' LDS entries, which earlier chunks (other waves) fill in.
-constexpr int RP_NW = 8;
+constexpr int RP_NW = 16;
 constexpr int16_t RP_UNSET = (int16_t)0x7fff;
 
 __global__ __launch_bounds__(64 * RP_NW) void k_unwrap_replay(const float *__restrict__ wrapped_all, const uint32_t *__restrict__ order_all,
