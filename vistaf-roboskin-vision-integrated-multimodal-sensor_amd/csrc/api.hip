@@ -627,12 +627,13 @@ int vistaf_ftp_predict_batch(vistaf_ftp_handle *hd, const void *d_frames, int fo
     if (timed) hipEventRecord(hd->ev[ST_COMPOSE], st);
     bool use_band = c.frontier_zero_band_px > 0;
     float band = (float)c.frontier_zero_band_px;
-    if (use_band) launch_chamfer(hd->reliable, false, hd->rowdist, hd->dist, B, h, w, c.frontier_zero_band_px + 2, st);
+    // both distance transforms of the reliable mask (to its outside for the taper, to its inside for the final blend) in one launch; the
+    // second one lands in planes that are idle at this point (`area` as the integer temporary, `depth` -- written by to_mm below)
+    if (use_band) launch_chamfer_pair(hd->reliable, hd->rowdist, hd->dist, hd->area, hd->depth, B, h, w, c.frontier_zero_band_px + 2, st);
     else HIPCHK(hipMemsetAsync(hd->dist, 0x7f, (size_t)B * P * sizeof(float), st));   // huge distance: taper weight 1
     launch_frontier_compose(hd->hmap, hd->reliable, hd->roi, hd->dist, use_band ? band : 1.0f, hd->z0f, hd->status, B, P, st);
     if (hd->g_unrel.k) blur(hd, hd->z0f, hd->snum, hd->g_unrel, B, st);
-    if (use_band) launch_chamfer(hd->reliable, true, hd->rowdist, hd->dist, B, h, w, c.frontier_zero_band_px + 2, st);
-    launch_finalize_unitless(hd->z0f, hd->g_unrel.k ? hd->snum : nullptr, hd->roi_den, hd->reliable, hd->roi, hd->dist, band, use_band ? 1 : 0,
+    launch_finalize_unitless(hd->z0f, hd->g_unrel.k ? hd->snum : nullptr, hd->roi_den, hd->reliable, hd->roi, use_band ? hd->depth : hd->dist, band, use_band ? 1 : 0,
                              hd->unitless, B, P, st);
 
     // ---- unitless -> mm, blob filter (shape_ftp.py:1850-1873)

@@ -354,10 +354,13 @@ __device__ inline int ch2_scan_min_up(int v)
 
 template <int PPL>
 __global__ __launch_bounds__(64) void k_chamfer2(const uint8_t *__restrict__ src_all, int invert, int32_t *__restrict__ tmp_all,
-                                                 float *__restrict__ dist_all, int h, int w)
+                                                 float *__restrict__ dist_all, int32_t *__restrict__ tmp2_all, float *__restrict__ dist2_all, int B,
+                                                 int h, int w)
 {
+    // workgroups [B, 2B) (launch_chamfer_pair): the distance to the complementary set of the same frames, into the second pair of planes
     const int lane = threadIdx.x;
-    const size_t b = blockIdx.x;
+    size_t b = blockIdx.x;
+    if (b >= (size_t)B) { b -= B; invert = !invert; tmp_all = tmp2_all; dist_all = dist2_all; }
     const size_t P = (size_t)h * w;
     const uint8_t *src = src_all + b * P;
     int32_t *tmp = tmp_all + b * P;
@@ -560,12 +563,29 @@ void launch_chamfer(const uint8_t *src, bool invert, int32_t *rowdist, float *di
         return;
     }
     (void)cap_px;
-    if (w <= 256) { hipLaunchKernelGGL(k_chamfer2<4>, dim3(B), dim3(64), 0, st, src, invert ? 1 : 0, rowdist, dist, h, w); return; }
-    if (w <= 512) { hipLaunchKernelGGL(k_chamfer2<8>, dim3(B), dim3(64), 0, st, src, invert ? 1 : 0, rowdist, dist, h, w); return; }
+    if (w <= 256) { hipLaunchKernelGGL(k_chamfer2<4>, dim3(B), dim3(64), 0, st, src, invert ? 1 : 0, rowdist, dist, nullptr, nullptr, B, h, w); return; }
+    if (w <= 512) { hipLaunchKernelGGL(k_chamfer2<8>, dim3(B), dim3(64), 0, st, src, invert ? 1 : 0, rowdist, dist, nullptr, nullptr, B, h, w); return; }
     // wider frames: closed form of the same two passes, exact up to cap_px (all that the callers look at)
     int rows = B * h;
     hipLaunchKernelGGL(k_rowdist, dim3((rows + 63) / 64), dim3(64), 0, st, src, invert ? 1 : 0, rowdist, h, w, B);
     hipLaunchKernelGGL(k_chamfer_cols, dim3((w + 255) / 256, h, B), dim3(256), 0, st, rowdist, dist, h, w, cap);
+}
+
+// distance to the zero pixels (-> dist_a) and to the non-zero pixels (-> dist_b) of the same masks.  The two-pass kernel is one wave per
+// frame, so both transforms of a batch run side by side in ONE launch of 2B workgroups (the chip holds four times that many waves).
+void launch_chamfer_pair(const uint8_t *src, int32_t *tmp_a, float *dist_a, int32_t *tmp_b, float *dist_b, int B, int h, int w, int cap_px,
+                         hipStream_t st)
+{
+    int cap = (int)((cap_px + 2) / 0.955) + 2;
+    if (cap > h) cap = h;
+    const bool two_pass = (getenv("VISTAF_CHAMFER_TWOPASS") || cap > 16 || (size_t)h * w * 2 > 150 * 1024) && w <= 512;
+    if (!two_pass) {
+        launch_chamfer(src, false, tmp_a, dist_a, B, h, w, cap_px, st);
+        launch_chamfer(src, true, tmp_b, dist_b, B, h, w, cap_px, st);
+        return;
+    }
+    if (w <= 256) hipLaunchKernelGGL(k_chamfer2<4>, dim3(2 * B), dim3(64), 0, st, src, 0, tmp_a, dist_a, tmp_b, dist_b, B, h, w);
+    else hipLaunchKernelGGL(k_chamfer2<8>, dim3(2 * B), dim3(64), 0, st, src, 0, tmp_a, dist_a, tmp_b, dist_b, B, h, w);
 }
 
 __global__ void k_erode_by_dist(const float *__restrict__ dist, const uint8_t *__restrict__ src, float margin, uint8_t *__restrict__ out, size_t n)

@@ -52,6 +52,8 @@ void launch_cc_label(const uint8_t *mask, int32_t *labels, int B, int h, int w, 
 void launch_cc_largest(const int32_t *labels, int32_t *area_scratch, unsigned long long *best, const uint8_t *and_static,
                        uint8_t *out, int B, int P, hipStream_t st);
 void launch_chamfer(const uint8_t *src, bool invert, int32_t *rowdist, float *dist, int B, int h, int w, int cap_px, hipStream_t st);
+void launch_chamfer_pair(const uint8_t *src, int32_t *tmp_a, float *dist_a, int32_t *tmp_b, float *dist_b, int B, int h, int w, int cap_px,
+                         hipStream_t st);
 void launch_erode_by_dist(const float *dist, const uint8_t *src, float margin, uint8_t *out, int B, int P, hipStream_t st);
 
 // ---- k_inpaint.hip ----------------------------------------------------------------------------
