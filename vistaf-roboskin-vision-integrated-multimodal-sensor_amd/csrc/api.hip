@@ -115,6 +115,30 @@ int make_gkern(vistaf_ftp_handle *hd, double sigma, GKern *g)
     return 0;
 }
 
+// Row spans of the set { (dx, dy) : 3x3 chamfer metric <= margin } (integer metric of cv::distanceTransform DIST_L2 3x3: 0.955 -> 62587,
+// 1.3693 -> 89738 in 1/65536 units; dist = c / 65536 as float, exact, so "dist <= margin" is "c <= margin * 65536").  false: too large.
+bool chamfer_ball(float margin, RowSpanSE *se)
+{
+    const long long HV = 62587, DG = 89738;
+    const long long M = (long long)std::floor((double)margin * 65536.0);
+    if (M < 0) return false;
+    const int R = (int)(M / HV);
+    if (2 * R + 1 > 33 || R > 63) return false;
+    se->k = std::max(3, 2 * R + 1);
+    const int r = se->k / 2;
+    for (int i = 0; i < se->k; i++) {
+        const int dy = std::abs(i - r);
+        int a = -1;
+        for (int dx = 0; dx <= 63; dx++) {
+            const long long mn = std::min(dx, dy), mx = std::max(dx, dy);
+            if (HV * (mx - mn) + DG * mn <= M) a = dx; else break;
+        }
+        if (a < 0) { se->lo[i] = 1; se->hi[i] = -1; }       // empty row
+        else { se->lo[i] = (int8_t)-a; se->hi[i] = (int8_t)a; }
+    }
+    return true;
+}
+
 int make_se(int k, RowSpanSE *se)
 {
     k = std::max(3, k | 1);
@@ -570,8 +594,16 @@ int vistaf_ftp_predict_batch(vistaf_ftp_handle *hd, const void *d_frames, int fo
         launch_cc_largest(hd->labels, hd->area, nullptr, hd->roi, hd->rel2, B, P, st);
     }
     if (c.reliable_edge_margin_px > 0) {
-        launch_chamfer(hd->rel2, false, hd->rowdist, hd->dist, B, h, w, c.reliable_edge_margin_px + 1, st);
-        launch_erode_by_dist(hd->dist, hd->rel2, (float)c.reliable_edge_margin_px, hd->reliable, B, P, st);
+        // erode_by_distance (shape_ftp.py:368-377): keep a pixel when its 3x3-chamfer distance to the nearest zero pixel exceeds the margin,
+        // i.e. when no zero pixel lies in the chamfer ball of that radius: an erosion by the ball (image border: nothing to erode, as in
+        // cv::distanceTransform where the outside holds no zero pixel).  The ball is a symmetric row-span element: bit-plane kernel.
+        RowSpanSE ball;
+        if (chamfer_ball((float)c.reliable_edge_margin_px, &ball))
+            launch_morph(hd->rel2, hd->reliable, B, h, w, ball, false, nullptr, nullptr, st, hd->morph_pre);
+        else {
+            launch_chamfer(hd->rel2, false, hd->rowdist, hd->dist, B, h, w, c.reliable_edge_margin_px + 1, st);
+            launch_erode_by_dist(hd->dist, hd->rel2, (float)c.reliable_edge_margin_px, hd->reliable, B, P, st);
+        }
     } else HIPCHK(hipMemcpyAsync(hd->reliable, hd->rel2, (size_t)B * P, hipMemcpyDeviceToDevice, st));
     launch_count_u8(hd->reliable, hd->rel_count, B, P, st);
     launch_mark_empty(hd->rel_count, hd->status, B, st);
