@@ -210,8 +210,8 @@ bool unwrap_ranked_supported(int h, int w);
 bool launch_unwrap_ranked(const float *quality, const uint8_t *mask, uint32_t *g0, uint32_t *g1, uint32_t *g2, uint32_t *g3,
                           int32_t *ppar, size_t gstride, uint16_t *rank16, int32_t *seed, int32_t *status, int B, int h, int w,
                           hipStream_t st, hipEvent_t ev_flood);
-void launch_unwrap_replay(const float *wrapped, const uint32_t *order, size_t ostride, int32_t *tree, float *unwrapped, int B, int h, int w,
-                          hipStream_t st);
+void launch_unwrap_replay(const float *wrapped, const uint32_t *order, size_t ostride, const int32_t *ppar, size_t gstride, int32_t *tree,
+                          float *unwrapped, int B, int h, int w, hipStream_t st);
 
 static int unwrap_lds_cap(int P)
 {
@@ -242,7 +242,7 @@ void launch_unwrap(const float *wrapped, const float *quality, const uint8_t *ma
         ppar = (const int32_t *)g4;
         if (logged) {
             if (ev_mid) hipEventRecord(ev_mid, st);
-            launch_unwrap_replay(wrapped, g2, 2 * EN, parent, unwrapped, B, h, w, st);
+            launch_unwrap_replay(wrapped, g2, 2 * EN, ppar, EN, parent, unwrapped, B, h, w, st);
             return;
         }
     } else if (cap > 0) {

@@ -243,8 +243,9 @@ constexpr int RP_NW = 16;
 constexpr int16_t RP_UNSET = (int16_t)0x7fff;
 
 __global__ __launch_bounds__(64 * RP_NW) void k_unwrap_replay(const float *__restrict__ wrapped_all, const uint32_t *__restrict__ order_all,
-                                                              size_t ostride, int32_t *__restrict__ tree_all, float *__restrict__ unwrapped_all,
-                                                              int h, int w, uint32_t magic)
+                                                              size_t ostride, const int32_t *__restrict__ ppar_all, size_t gstride,
+                                                              int32_t *__restrict__ tree_all, float *__restrict__ unwrapped_all, int h, int w,
+                                                              uint32_t magic)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     int16_t *ks = (int16_t *)lds_raw;                                     // [EN8]
@@ -282,22 +283,36 @@ __global__ __launch_bounds__(64 * RP_NW) void k_unwrap_replay(const float *__res
             v = (int)k;
         }
         bool done = !valid;
-        int kf = 0;
         if (valid && pp == idx) { done = true; __hip_atomic_store(&ks[idx], (int16_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
         while (__ballot(!done)) {
             if (!done) {
                 int16_t kq = __hip_atomic_load(&ks[pp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (kq != RP_UNSET) {
-                    kf = (int)kq + v;
+                    const int kf = (int)kq + v;
                     __hip_atomic_store(&ks[idx], (int16_t)kf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     done = true;
                 }
             }
         }
-        if (valid) {
-            unwrapped[p] = (float)((double)wp + twopi * (double)kf);
-            tree[p] = par;
+    }
+    // the two result planes in pixel order (coalesced; the walk above writes nothing to memory): unwrapped = wrapped + 2*pi*k, parent in
+    // frame coordinates; NaN / -1 where the growth never arrived
+    __syncthreads();
+    const int32_t *ppar = ppar_all + b * gstride;
+    for (int p = tid; p < P; p += 64 * RP_NW) {
+        const int y = p / w, x = p - y * w;
+        const int idx = (y + 1) * W2 + x + 1;
+        const int16_t kq = ks[idx];
+        float u = __uint_as_float(0x7fc00000u);
+        int par = -1;
+        if (kq != RP_UNSET) {
+            u = (float)((double)wrapped[p] + twopi * (double)kq);
+            const int pp = ppar[idx];
+            const int py = (int)__umulhi((uint32_t)pp, magic), px = pp - py * W2;
+            par = (py - 1) * w + (px - 1);
         }
+        unwrapped[p] = u;
+        tree[p] = par;
     }
 }
 
@@ -320,18 +335,15 @@ void launch_unwrap_flood_batch(const uint16_t *rank16, const int32_t *seed, cons
 }
 
 // unwrapped = wrapped + 2*pi*k along the growth tree; NaN / parent -1 where the growth never arrived
-void launch_unwrap_replay(const float *wrapped, const uint32_t *order, size_t ostride, int32_t *tree, float *unwrapped, int B, int h, int w,
-                          hipStream_t st)
+void launch_unwrap_replay(const float *wrapped, const uint32_t *order, size_t ostride, const int32_t *ppar, size_t gstride, int32_t *tree,
+                          float *unwrapped, int B, int h, int w, hipStream_t st)
 {
-    const size_t n = (size_t)B * h * w;
-    (void)hipMemsetAsync(tree, 0xff, n * sizeof(int32_t), st);
-    (void)hipMemsetD32Async((hipDeviceptr_t)unwrapped, 0x7fc00000, n, st);
     long EN = (long)(h + 2) * (w + 2);
     size_t lds = (size_t)(((EN + 7) & ~7L)) * 2;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_unwrap_replay, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
     const uint32_t magic = (uint32_t)(0x100000000ull / (unsigned)(w + 2)) + 1u;
-    hipLaunchKernelGGL(k_unwrap_replay, dim3(B), dim3(64 * RP_NW), lds, st, wrapped, order, ostride, tree, unwrapped, h, w, magic);
+    hipLaunchKernelGGL(k_unwrap_replay, dim3(B), dim3(64 * RP_NW), lds, st, wrapped, order, ostride, ppar, gstride, tree, unwrapped, h, w, magic);
 }
 
 }  // namespace vf
