@@ -158,8 +158,7 @@ int make_se(int k, RowSpanSE *se)
 
 void blur(vistaf_ftp_handle *hd, const float *src, float *dst, const GKern &g, int B, hipStream_t st)
 {
-    launch_gauss_rows(src, hd->tmpf, g.d, g.k, B, hd->h, hd->w, st);
-    launch_gauss_cols(hd->tmpf, dst, g.d, g.k, B, hd->h, hd->w, st);
+    launch_gauss_blur(src, hd->tmpf, dst, g.d, g.k, B, hd->h, hd->w, st);
 }
 
 float q32_of(double pct) { return (float)pct / 100.0f; }   // np.true_divide(q, float32(100))

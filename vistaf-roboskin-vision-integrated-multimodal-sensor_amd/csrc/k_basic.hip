@@ -448,6 +448,67 @@ void launch_gauss_cols(const float *src, float *dst, const float *kern, int ksiz
     hipLaunchKernelGGL(k_gauss_cols, grid, dim3(256), 0, st, src, dst, kern, ksize, h, w);
 }
 
+// Both passes in one kernel for short kernels (ksize <= GF_MAXK): a 64 x 32 output tile with its halo goes through LDS once -- row pass
+// into a second LDS plane (rounded to float exactly as the intermediate plane of the two-kernel path is), column pass out of it -- so the
+// intermediate plane never travels to memory.  Same taps, same order of the fused multiply-adds per output: same bits as the two kernels.
+constexpr int GF_TX = 64, GF_TY = 32, GF_MAXK = 15;
+__global__ __launch_bounds__(256) void k_gauss_fused(const float *__restrict__ src, float *__restrict__ dst, const float *__restrict__ kern,
+                                                     int ksize, int h, int w)
+{
+    __shared__ float in_t[(GF_TY + GF_MAXK - 1) * (GF_TX + GF_MAXK - 1)];
+    __shared__ float mid_t[(GF_TY + GF_MAXK - 1) * GF_TX];
+    const int r = ksize / 2;
+    const int tw = GF_TX + 2 * r, th = GF_TY + 2 * r;
+    const int x0 = blockIdx.x * GF_TX, y0 = blockIdx.y * GF_TY;
+    const size_t b = blockIdx.z;
+    const float *plane = src + b * (size_t)h * w;
+    for (int i = threadIdx.x; i < tw * th; i += 256) {
+        const int ty = i / tw, tx = i - ty * tw;
+        in_t[i] = plane[(size_t)reflect101(y0 + ty - r, h) * w + reflect101(x0 + tx - r, w)];
+    }
+    __syncthreads();
+    // row pass: th rows x 64 columns
+    for (int i = threadIdx.x; i < th * GF_TX; i += 256) {
+        const int ty = i >> 6, tx = i & 63;
+        const float *t = in_t + ty * tw + tx;
+        float acc = kern[0] * t[0];
+        for (int j = 1; j < ksize; j++) acc = fmaf(kern[j], t[j], acc);
+        mid_t[i] = acc;
+    }
+    __syncthreads();
+    // column pass: a thread slides over GC_R output rows of one column (taps outside the kernel are zero: see k_gauss_cols_lds)
+    const int tx = threadIdx.x & 63, tg = threadIdx.x >> 6;
+    const int x = x0 + tx, yb = y0 + tg * GC_R;
+    if (x >= w || yb >= h) return;
+    float acc[GC_R], kw[GC_R];
+#pragma unroll
+    for (int o = 0; o < GC_R; o++) { acc[o] = 0.f; kw[o] = 0.f; }
+    const float *t0 = mid_t + (tg * GC_R) * GF_TX + tx;
+    for (int j = 0; j < ksize + GC_R - 1; j++) {
+        const float v = t0[j * GF_TX];
+#pragma unroll
+        for (int o = GC_R - 1; o > 0; o--) kw[o] = kw[o - 1];
+        kw[0] = j < ksize ? kern[j] : 0.f;
+#pragma unroll
+        for (int o = 0; o < GC_R; o++) acc[o] = fmaf(kw[o], v, acc[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < GC_R; o++)
+        if (yb + o < h) dst[b * (size_t)h * w + (size_t)(yb + o) * w + x] = acc[o];
+}
+
+// separable blur src -> dst (tmp: intermediate plane of the two-kernel path)
+void launch_gauss_blur(const float *src, float *tmp, float *dst, const float *kern, int ksize, int B, int h, int w, hipStream_t st)
+{
+    static_assert(GF_TY == 4 * GC_R, "four waves of GC_R rows");
+    if (ksize <= GF_MAXK && src != dst) {
+        hipLaunchKernelGGL(k_gauss_fused, dim3((w + GF_TX - 1) / GF_TX, (h + GF_TY - 1) / GF_TY, B), dim3(256), 0, st, src, dst, kern, ksize, h, w);
+        return;
+    }
+    launch_gauss_rows(src, tmp, kern, ksize, B, h, w, st);
+    launch_gauss_cols(tmp, dst, kern, ksize, B, h, w, st);
+}
+
 // ------------------------------------------------------------------------------------------------
 __global__ void k_illum_norm(const float *__restrict__ img, const float *__restrict__ blur, float *__restrict__ out, size_t n)
 {

@@ -23,6 +23,7 @@ void launch_morph(const uint8_t *src, uint8_t *dst, int B, int h, int w, const R
 void launch_morph_seq(const uint8_t *src, uint8_t *dst, uint8_t *tmp, int B, int h, int w, const RowSpanSE &se, const int *dilates, int n,
                       const uint8_t *and_static, const uint8_t *and_frame, hipStream_t st, uint16_t *prefix_scratch = nullptr);
 void launch_gauss_rows(const float *src, float *dst, const float *kern, int ksize, int B, int h, int w, hipStream_t st);
+void launch_gauss_blur(const float *src, float *tmp, float *dst, const float *kern, int ksize, int B, int h, int w, hipStream_t st);
 void launch_gauss_cols(const float *src, float *dst, const float *kern, int ksize, int B, int h, int w, hipStream_t st);
 void launch_illum_norm(const float *img, const float *blur, float *out, int B, int P, hipStream_t st);
 void launch_mul_static(const float *a, const float *stat, float *out, int B, int P, hipStream_t st);
