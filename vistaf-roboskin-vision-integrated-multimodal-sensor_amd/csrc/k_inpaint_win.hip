@@ -27,6 +27,7 @@
 
 namespace vf {
 
+constexpr int WN_RING_U = 6;         // inpaint ranges up to this have their ring taps unrolled (independent loads)
 constexpr int WN_QCAP = 4096;       // live queue entries (8 B each)
 constexpr int WN_CELLS = 14464;     // window cells (9 B each: T f32, image f32, flags u8)
 
@@ -111,24 +112,48 @@ __device__ inline bool wn_march(float *__restrict__ img, const uint8_t *__restri
     for (int r = 0; r < wh; r++)
         for (int cc = lane; cc < ww; cc += 64) {
             int li = r * ww + cc;
-            int lo = max(0, cc - range), hi = min(ww - 1, cc + range);
+            // the taps are independent loads issued together (a plain loop over [cc - range, cc + range] is one dependent LDS round trip
+            // per tap on this lone wave)
             uint8_t any = 0;
-            for (int c2 = lo; c2 <= hi; c2++) any |= f[r * ww + c2];
+            if (range <= WN_RING_U) {
+#pragma unroll
+                for (int d = -WN_RING_U; d <= WN_RING_U; d++) {
+                    const int c2 = cc + d;
+                    const bool in = d >= -range && d <= range && c2 >= 0 && c2 < ww;
+                    const uint8_t v = f[r * ww + (in ? c2 : cc)];
+                    any |= in ? v : (uint8_t)0;
+                }
+            } else {
+                int lo = max(0, cc - range), hi = min(ww - 1, cc + range);
+                for (int c2 = lo; c2 <= hi; c2++) any |= f[r * ww + c2];
+            }
             if (any & W_HOLE) f[li] |= W_ROW;      // neighbours only look at bit 6, which this never changes
         }
     __builtin_amdgcn_wave_barrier();
     for (int r = 0; r < wh; r++)
         for (int cc = lane; cc < ww; cc += 64) {
             int li = r * ww + cc;
-            uint8_t me = f[li];
-            if (me & (W_BORDER | W_HOLE)) continue;                            // hole pixels are KNOWN for the outside pass
-            // window edge cells are at distance range+1 from the hole: never band, their neighbours are not needed
-            bool band = (cc > 0 && (f[li - 1] & W_HOLE)) || (cc < ww - 1 && (f[li + 1] & W_HOLE)) ||
-                        (r > 0 && (f[li - ww] & W_HOLE)) || (r < wh - 1 && (f[li + ww] & W_HOLE));
-            if (band) { f[li] = me | W_SEED; t[li] = 0.f; continue; }
-            int lo = max(0, r - range), hi = min(wh - 1, r + range);
+            // every read of the cell is issued up front (clamped indices instead of short-circuit tests: those are dependent round trips)
+            const uint8_t me = f[li];
+            const uint8_t nl = f[cc > 0 ? li - 1 : li], nr = f[cc < ww - 1 ? li + 1 : li], nu = f[r > 0 ? li - ww : li], nd = f[r < wh - 1 ? li + ww : li];
             uint8_t any = 0;
-            for (int r2 = lo; r2 <= hi; r2++) any |= f[r2 * ww + cc];
+            if (range <= WN_RING_U) {
+#pragma unroll
+                for (int d = -WN_RING_U; d <= WN_RING_U; d++) {
+                    const int r2 = r + d;
+                    const bool in = d >= -range && d <= range && r2 >= 0 && r2 < wh;
+                    const uint8_t v = f[(in ? r2 : r) * ww + cc];
+                    any |= in ? v : (uint8_t)0;
+                }
+            } else {
+                int lo = max(0, r - range), hi = min(wh - 1, r + range);
+                for (int r2 = lo; r2 <= hi; r2++) any |= f[r2 * ww + cc];
+            }
+            if (me & (W_BORDER | W_HOLE)) continue;                            // hole pixels are KNOWN for the outside pass
+            // window edge cells are at distance range+1 from the hole: never band, their neighbours are not needed (a clamped index reads
+            // the cell itself, which is not a hole pixel here)
+            const bool band = ((nl | nr | nu | nd) & W_HOLE) != 0;
+            if (band) { f[li] = me | W_SEED; t[li] = 0.f; continue; }
             if (any & W_ROW) f[li] = me | W_INSIDE;                              // writes bits 0-1 only
         }
     __builtin_amdgcn_wave_barrier();
