@@ -27,6 +27,7 @@
 
 namespace vf {
 
+constexpr int WN_LOAD_U = 8;         // window cells per lane in flight while the window is loaded
 constexpr int WN_RING_U = 6;         // inpaint ranges up to this have their ring taps unrolled (independent loads)
 constexpr int WN_QCAP = 4096;       // live queue entries (8 B each)
 constexpr int WN_CELLS = 14464;     // window cells (9 B each: T f32, image f32, flags u8)
@@ -88,22 +89,36 @@ __device__ inline bool wn_march(float *__restrict__ img, const uint8_t *__restri
     const int cells = wh * ww;
     WSTAMP(0);
 
-    // ---- load window: hole / border bits, T = 1e6, image
-    for (int r = 0; r < wh; r++) {
-        const int gi = i0 + r;
-        const bool rowin = gi >= 1 && gi <= h;
-#pragma unroll 2
-        for (int cc = lane; cc < ww; cc += 64) {
-            int gj = j0 + cc;
-            bool interior = rowin && gj >= 1 && gj <= w;
-            size_t gp = interior ? (size_t)(gi - 1) * w + (gj - 1) : 0;
-            float v = img[gp];
-            uint8_t bd = bad[gp];
-            if (CL) bd = (bd && lab[gp] == rootp) ? 1 : 0;
-            int li = r * ww + cc;
-            im[li] = interior ? v : 0.f;
-            f[li] = !interior ? W_BORDER : bd ? W_HOLE : (uint8_t)0;
-            t[li] = 1.0e6f;
+    // ---- load window: hole / border bits, T = 1e6, image.  Cells in flat order, WN_LOAD_U per lane in flight (a row-by-row loop is one
+    // memory round trip per 64 cells on this lone wave)
+    {
+        const uint32_t mg_ww = (uint32_t)(0x100000000ull / (unsigned)ww) + 1u;       // li / ww == umulhi(li, mg_ww) for li < 2^16
+        for (int base = 0; base < cells; base += 64 * WN_LOAD_U) {
+            float v[WN_LOAD_U];
+            uint8_t bd[WN_LOAD_U];
+            int lab_v[WN_LOAD_U];
+            bool interior[WN_LOAD_U];
+#pragma unroll
+            for (int k = 0; k < WN_LOAD_U; k++) {
+                const int li = base + k * 64 + lane;
+                const int r = (int)__umulhi((uint32_t)li, mg_ww), cc = li - r * ww;
+                const int gi = i0 + r, gj = j0 + cc;
+                interior[k] = li < cells && gi >= 1 && gi <= h && gj >= 1 && gj <= w;
+                const size_t gp = interior[k] ? (size_t)(gi - 1) * w + (gj - 1) : 0;
+                v[k] = img[gp];
+                bd[k] = bad[gp];
+                lab_v[k] = CL ? lab[gp] : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < WN_LOAD_U; k++) {
+                const int li = base + k * 64 + lane;
+                if (li >= cells) continue;
+                uint8_t b8 = bd[k];
+                if (CL) b8 = (b8 && lab_v[k] == rootp) ? 1 : 0;
+                im[li] = interior[k] ? v[k] : 0.f;
+                f[li] = !interior[k] ? W_BORDER : b8 ? W_HOLE : (uint8_t)0;
+                t[li] = 1.0e6f;
+            }
         }
     }
     __builtin_amdgcn_wave_barrier();
