@@ -123,55 +123,77 @@ __device__ inline bool wn_march(float *__restrict__ img, const uint8_t *__restri
     }
     __builtin_amdgcn_wave_barrier();
     WSTAMP(1);
-    // ---- ring = within Chebyshev `range` of the hole (separable: rows, then columns)
-    for (int r = 0; r < wh; r++)
-        for (int cc = lane; cc < ww; cc += 64) {
-            int li = r * ww + cc;
-            // the taps are independent loads issued together (a plain loop over [cc - range, cc + range] is one dependent LDS round trip
-            // per tap on this lone wave)
-            uint8_t any = 0;
-            if (range <= WN_RING_U) {
+    // ---- ring = within Chebyshev `range` of the hole (separable: rows, then columns).  Cells in flat order, two per lane and iteration;
+    // every tap of a cell is an independent load (clamped index + select: a loop over [-range, range] or a short-circuit test would be one
+    // dependent LDS round trip per tap on this lone wave).
+    {
+        const uint32_t mg_ww = (uint32_t)(0x100000000ull / (unsigned)ww) + 1u;
+        const bool unrolled = range <= WN_RING_U;
+        for (int base = 0; base < cells; base += 128) {
+            uint8_t any[2], me[2];
 #pragma unroll
-                for (int d = -WN_RING_U; d <= WN_RING_U; d++) {
-                    const int c2 = cc + d;
-                    const bool in = d >= -range && d <= range && c2 >= 0 && c2 < ww;
-                    const uint8_t v = f[r * ww + (in ? c2 : cc)];
-                    any |= in ? v : (uint8_t)0;
-                }
-            } else {
-                int lo = max(0, cc - range), hi = min(ww - 1, cc + range);
-                for (int c2 = lo; c2 <= hi; c2++) any |= f[r * ww + c2];
-            }
-            if (any & W_HOLE) f[li] |= W_ROW;      // neighbours only look at bit 6, which this never changes
-        }
-    __builtin_amdgcn_wave_barrier();
-    for (int r = 0; r < wh; r++)
-        for (int cc = lane; cc < ww; cc += 64) {
-            int li = r * ww + cc;
-            // every read of the cell is issued up front (clamped indices instead of short-circuit tests: those are dependent round trips)
-            const uint8_t me = f[li];
-            const uint8_t nl = f[cc > 0 ? li - 1 : li], nr = f[cc < ww - 1 ? li + 1 : li], nu = f[r > 0 ? li - ww : li], nd = f[r < wh - 1 ? li + ww : li];
-            uint8_t any = 0;
-            if (range <= WN_RING_U) {
+            for (int k = 0; k < 2; k++) {
+                const int li = min(base + k * 64 + lane, cells - 1);
+                const int r = (int)__umulhi((uint32_t)li, mg_ww), cc = li - r * ww;
+                me[k] = f[li];
+                uint8_t a = 0;
+                if (unrolled) {
 #pragma unroll
-                for (int d = -WN_RING_U; d <= WN_RING_U; d++) {
-                    const int r2 = r + d;
-                    const bool in = d >= -range && d <= range && r2 >= 0 && r2 < wh;
-                    const uint8_t v = f[(in ? r2 : r) * ww + cc];
-                    any |= in ? v : (uint8_t)0;
+                    for (int d = -WN_RING_U; d <= WN_RING_U; d++) {
+                        const int c2 = cc + d;
+                        const bool in = d >= -range && d <= range && c2 >= 0 && c2 < ww;
+                        const uint8_t v = f[in ? li + d : li];
+                        a |= in ? v : (uint8_t)0;
+                    }
+                } else {
+                    const int lo = max(0, cc - range), hi = min(ww - 1, cc + range);
+                    for (int c2 = lo; c2 <= hi; c2++) a |= f[r * ww + c2];
                 }
-            } else {
-                int lo = max(0, r - range), hi = min(wh - 1, r + range);
-                for (int r2 = lo; r2 <= hi; r2++) any |= f[r2 * ww + cc];
+                any[k] = a;
             }
-            if (me & (W_BORDER | W_HOLE)) continue;                            // hole pixels are KNOWN for the outside pass
-            // window edge cells are at distance range+1 from the hole: never band, their neighbours are not needed (a clamped index reads
-            // the cell itself, which is not a hole pixel here)
-            const bool band = ((nl | nr | nu | nd) & W_HOLE) != 0;
-            if (band) { f[li] = me | W_SEED; t[li] = 0.f; continue; }
-            if (any & W_ROW) f[li] = me | W_INSIDE;                              // writes bits 0-1 only
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int li = base + k * 64 + lane;
+                if (li < cells && (any[k] & W_HOLE)) f[li] = me[k] | W_ROW;      // neighbours only look at bit 6, which this never changes
+            }
         }
-    __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_wave_barrier();
+        for (int base = 0; base < cells; base += 128) {
+            uint8_t any[2], me[2], nb4[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int li = min(base + k * 64 + lane, cells - 1);
+                const int r = (int)__umulhi((uint32_t)li, mg_ww), cc = li - r * ww;
+                me[k] = f[li];
+                // window edge cells are at distance range+1 from the hole: never band, their neighbours are not needed (a clamped index
+                // reads the cell itself, which only matters when it is not a hole pixel)
+                nb4[k] = f[cc > 0 ? li - 1 : li] | f[cc < ww - 1 ? li + 1 : li] | f[r > 0 ? li - ww : li] | f[r < wh - 1 ? li + ww : li];
+                uint8_t a = 0;
+                if (unrolled) {
+#pragma unroll
+                    for (int d = -WN_RING_U; d <= WN_RING_U; d++) {
+                        const int r2 = r + d;
+                        const bool in = d >= -range && d <= range && r2 >= 0 && r2 < wh;
+                        const uint8_t v = f[in ? li + d * ww : li];
+                        a |= in ? v : (uint8_t)0;
+                    }
+                } else {
+                    const int lo = max(0, r - range), hi = min(wh - 1, r + range);
+                    for (int r2 = lo; r2 <= hi; r2++) a |= f[r2 * ww + cc];
+                }
+                any[k] = a;
+            }
+            // reads of this iteration see W_ROW / W_HOLE only (bits 5 and 6), which the writes below never change
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int li = base + k * 64 + lane;
+                if (li >= cells || (me[k] & (W_BORDER | W_HOLE))) continue;     // hole pixels are KNOWN for the outside pass
+                if (nb4[k] & W_HOLE) { f[li] = me[k] | W_SEED; t[li] = 0.f; }
+                else if (any[k] & W_ROW) f[li] = me[k] | W_INSIDE;               // writes bits 0-1 only
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
 
     WSTAMP(2);
     TeleaWin win;
