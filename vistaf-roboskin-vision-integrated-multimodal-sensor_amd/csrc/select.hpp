@@ -12,7 +12,8 @@
 namespace vf {
 
 constexpr int SEL_T = 1024;
-constexpr int SEL_NB = 2048;
+constexpr int SEL_BITS = 13;          // histogram digits: 8192 buckets, 8 per thread in the bucket search
+constexpr int SEL_NB = 1 << SEL_BITS;
 constexpr int SEL_CAND = 1024;
 
 struct SelShared {
@@ -71,15 +72,18 @@ __device__ __attribute__((always_inline)) inline void block_select2_each(Each ea
         uint32_t range = hi - lo;
         if (range == 0) { a = lo; break; }
         int bits = 32 - __clz(range);
-        int shift = bits > 11 ? bits - 11 : 0;
+        int shift = bits > SEL_BITS ? bits - SEL_BITS : 0;
         for (int i = tid; i < SEL_NB; i += SEL_T) sh.hist[i] = 0;
         __syncthreads();
         each([&](uint32_t key) { if (key >= lo && key <= hi) atomicAdd(&sh.hist[(key - lo) >> shift], 1u); });
         __syncthreads();
-        // locate the bucket holding rank (k - below): each thread owns 2 buckets
+        // locate the bucket holding rank (k - below): each thread owns SEL_NB / SEL_T consecutive buckets
         uint32_t want = k - below;
-        uint32_t c0 = sh.hist[2 * tid], c1 = sh.hist[2 * tid + 1];
-        uint32_t mine = c0 + c1;
+        constexpr int NBT = SEL_NB / SEL_T;
+        uint32_t cb[NBT];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int j = 0; j < NBT; j++) { cb[j] = sh.hist[NBT * tid + j]; mine += cb[j]; }
         // exclusive prefix over threads: wave scan + wave totals
         int lane = tid & 63, wid = tid >> 6;
         uint32_t incl = wave_scan_add(mine);
@@ -89,8 +93,12 @@ __device__ __attribute__((always_inline)) inline void block_select2_each(Each ea
         for (int i = 0; i < wid; i++) wbase += sh.wsum[i];
         uint32_t excl = wbase + incl - mine;
         if (want >= excl && want < excl + mine) {
-            if (want < excl + c0) { sh.s_bucket = 2 * tid; sh.s_before = excl; sh.s_cnt = c0; }
-            else { sh.s_bucket = 2 * tid + 1; sh.s_before = excl + c0; sh.s_cnt = c1; }
+            uint32_t run = excl;
+#pragma unroll
+            for (int j = 0; j < NBT; j++) {
+                if (want >= run && want < run + cb[j]) { sh.s_bucket = NBT * tid + j; sh.s_before = run; sh.s_cnt = cb[j]; }
+                run += cb[j];
+            }
         }
         __syncthreads();
         uint32_t bsel = sh.s_bucket, cnt = sh.s_cnt;
