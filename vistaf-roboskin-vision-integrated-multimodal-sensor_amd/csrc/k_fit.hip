@@ -127,9 +127,29 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit(const float *__restric
     // of the fit then read 4 B per pixel instead of 5 (they run at HBM / Infinity-Cache speed: 256 frames do not fit the L2s).  Every
     // thread only ever touches the pixels tid, tid + 1024, ...: its own stores, so no fence is needed.
     float *zc = resid_all + b * (size_t)P;
-    for (int p = tid; p < P; p += SEL_T) {
-        const float zz = z[p];
-        zc[p] = (m[p] && finitef(zz)) ? zz : __uint_as_float(0x7fc00000u);
+    // the same pass counts the fitted pixels and finds the range of z (coefficients are still zero: r = z)
+    uint32_t cnt0 = 0;
+    unsigned long long mn0 = ~0ull, mx0 = 0;
+    {
+        int p = tid;
+        for (; p + (FIT_U - 1) * SEL_T < P; p += FIT_U * SEL_T) {
+            float zz[FIT_U];
+            uint8_t mk[FIT_U];
+#pragma unroll
+            for (int u = 0; u < FIT_U; u++) { zz[u] = z[p + u * SEL_T]; mk[u] = m[p + u * SEL_T]; }
+#pragma unroll
+            for (int u = 0; u < FIT_U; u++) {
+                const bool ok = mk[u] && finitef(zz[u]);
+                zc[p + u * SEL_T] = ok ? zz[u] : __uint_as_float(0x7fc00000u);
+                if (ok) { const uint32_t key = f2key(zz[u]); cnt0++; if (key < mn0) mn0 = key; if (key + 1ull > mx0) mx0 = key + 1ull; }
+            }
+        }
+        for (; p < P; p += SEL_T) {
+            const float zz = z[p];
+            const bool ok = m[p] && finitef(zz);
+            zc[p] = ok ? zz : __uint_as_float(0x7fc00000u);
+            if (ok) { const uint32_t key = f2key(zz); cnt0++; if (key < mn0) mn0 = key; if (key + 1ull > mx0) mx0 = key + 1ull; }
+        }
     }
     FitCtx ctx;
     ctx.z = zc; ctx.m = m; ctx.tab = s_tab; ctx.use_tab = use_tab; ctx.w = w; ctx.magic = magic; ctx.cxf = cxf; ctx.cyf = cyf;
@@ -138,7 +158,14 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit(const float *__restric
 
     // ---- number of fitted pixels (mask != 0 and finite z) and the range of z (coefficients are still zero: r = z)
     uint32_t n, zkmin, zkmax;
-    block_minmax(ctx, P, sh, n, zkmin, zkmax);
+    {
+        __syncthreads();
+        n = block_sum<uint32_t>(cnt0, sh.wsum);
+        mn0 = block_min_u64(mn0, sh.red64);
+        mx0 = block_max_u64(mx0, sh.red64);
+        zkmin = (uint32_t)mn0; zkmax = mx0 ? (uint32_t)(mx0 - 1) : 0;
+        __syncthreads();
+    }
     const float zmin = key2f(zkmin), zmax = key2f(zkmax);
     const bool do_fit = (int)n >= min_count;
 
