@@ -178,6 +178,17 @@ def main():
                 traffic = json.load(open(tp)).get(dom)
             except Exception:
                 traffic = None
+        # the other two heavy stages, for context: measured HBM traffic (profiles/traffic_r01.json) over this run's stage time
+        other = []
+        try:
+            tj = json.load(open(tp)) if os.path.exists(tp) else {}
+        except Exception:
+            tj = {}
+        for k in ("unwrap flood (k_unwrap_flood_batch)", "detrend (3x IRLS)", "inpaint (k_telea_window)"):
+            if k != dom and k in acc and isinstance(tj.get(k), (int, float)) and acc[k] > 0:
+                rate = tj[k] / (acc[k] * 1e-3) / 1e9
+                other.append({"kernel": k, "kernel_ms": round(acc[k], 4), "traffic": tj[k], "hbm_GBps": round(rate, 1),
+                              "frac_of_hbm_peak": round(rate / HBM_PEAK_GBS, 4)})
         line = {
             "metric": "frames/sec (224x224 -> force-map) at batch 256",
             "value": world * B * args.steps / elapsed,
@@ -203,6 +214,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel_ms": acc[dom], "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "dominant stage is latency-bound (a sequential fast-marching / priority-queue march, one wave per frame), not bandwidth-bound",
+                "other_heavy_stages": other,
             },
             "stage_ms": {k: round(v, 4) for k, v in acc.items()},
             "serial_ms_per_step": round(sum(acc.values()), 4),
