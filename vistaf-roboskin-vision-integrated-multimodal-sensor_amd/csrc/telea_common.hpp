@@ -326,15 +326,15 @@ __device__ __attribute__((always_inline)) inline int telea_pop_outside4(const Te
         }
         commit(m);                            // the m entries leave the queue before their pushes enter it
         if (g < m && (lane & 15) == 0) f[p] = (uint8_t)(seed ? (W_SEED | W_CHANGE) : W_CHANGE);   // ring pixels carry no other bit that matters
-        // pushes in the order of the sequential loop: pop by pop, neighbour by neighbour = ascending lane among the quad leaders
+        // the new band pixels are distinct cells (four neighbours of a pop; pops of a batch are >= 4 apart): their quad leaders store
+        // T and the state together; only the queue insertions are ordered
         unsigned long long pb = okb & 0x1111111111111111ull;
+        if ((pb >> lane) & 1ull) { t[pn] = dist; f[pn] = W_BAND; }
+        // pushes in the order of the sequential loop: pop by pop, neighbour by neighbour = ascending lane among the quad leaders
         while (pb) {
             const int l = __ffsll((long long)pb) - 1;
             pb &= pb - 1ull;
-            const float dk = wn_lane_f(dist, l);
-            const int pk = __builtin_amdgcn_readlane(pn, l);
-            if (lane == 0) { t[pk] = dk; f[pk] = W_BAND; }
-            push(dk, pk);
+            push(wn_lane_f(dist, l), __builtin_amdgcn_readlane(pn, l));
         }
     } else {
         commit(m);
