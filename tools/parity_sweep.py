@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""GPU vs oracle on many synthetic frames: per-frame height-map and scalar deviations (diagnostic; run on the GPU box).
+usage: python tools/parity_sweep.py [count] [start] [amp_scale]"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("vistaf-roboskin-vision-integrated-multimodal-sensor_amd")
+from oracle import ftp_oracle as O  # noqa: E402
+
+G = os.path.join(ROOT, "tests", "golden")
+nb = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+start = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+amp = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
+n = 224
+cfg = pkg.FtpConfig.scaled(n)
+cal, neg = pkg.load_calibration(os.path.join(G, "calibration_phase_to_height.json"))
+fm = pkg.load_force_calibration(os.path.join(G, "calibration_height_to_force.json"))["best_model"]
+ref = pkg.synth.reference_frame(n, config=3)
+frames = pkg.synth.deformed_batch(n, start, nb, config=3, amp_scale=amp)
+sensor = pkg.FtpSensor(ref, pkg.synth.roi_circle(n), cfg, cal, neg, fm, max_batch=nb)
+out = sensor.predict_batch(frames)
+torch.cuda.synchronize()
+rs = O.make_reference_state(ref, *pkg.synth.roi_circle(n), cfg)
+worst = (0, 0, 0)
+for b in range(nb):
+    o = O.process_frame(frames[b], rs, cfg, cal, neg, fm)
+    hm = out["height_map_mm"][b].cpu().numpy()
+    r = o["height_map_mm_crop"]
+    same_nan = np.array_equal(np.isnan(hm), np.isnan(r))
+    peak = max(float(np.nanmax(np.abs(r))), 1e-6)
+    d = float(np.nanmax(np.abs(hm - r))) / peak
+    s = out["scalars"][b].cpu().numpy()
+    dv = abs(s[0] - o["volume_cm3"]) / max(abs(o["volume_cm3"]), 1e-9)
+    da = abs(s[1] - o["contact_area_mm2"]) / max(abs(o["contact_area_mm2"]), 1e-9)
+    dm = abs(s[2] - o["max_depth_mm"]) / max(abs(o["max_depth_mm"]), 1e-9)
+    npx = int(np.sum(np.abs(hm - r) > 0.25 * np.nanmax(np.abs(hm - r)))) if d > 0 else 0
+    print("frame %3d nan_equal %s map %.2e vol %.2e area %.2e maxd %.2e argmax_eq %s px_near_worst %d" % (
+        start + b, same_nan, d, dv, da, dm, int(s[4]) == o["argmax_depth_index"], npx))
