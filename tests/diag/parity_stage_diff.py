@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Stage-by-stage GPU vs oracle comparison of ONE synthetic frame (diagnostic; run on the GPU box).
-usage: python tools/parity_stage_diff.py <frame_seed> [amp_scale]"""
+usage: python tests/diag/parity_stage_diff.py <frame_seed> [amp_scale]"""
 import importlib
 import os
 import sys
@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("vistaf-roboskin-vision-integrated-multimodal-sensor_amd")
 from oracle import ftp_oracle as O  # noqa: E402
