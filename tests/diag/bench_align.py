@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """Timing of the GPU pre-path alignment (N2) on the FINAL_E photograph pair: ms per frame, ECC iterations, and the CPU
-restatement (oracle/align_oracle.py) beside it.  python tools/bench_align.py [batch]"""
+restatement (oracle/align_oracle.py) beside it.  python tests/diag/bench_align.py [batch]"""
 import importlib, json, os, sys, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("vistaf-roboskin-vision-integrated-multimodal-sensor_amd")
 from PIL import Image
