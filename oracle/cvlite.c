@@ -84,8 +84,18 @@ void cvl_gaussian_kernel_f32(int n, double sigma, float *out)
 }
 
 /* Separable filter, BORDER_REFLECT_101, float accumulation.
- * Row pass: ascending-k sum (cv::RowFilter); column pass: symmetric form
- * k[c]*S[c] + sum_j k[c+j]*(S[c+j]+S[c-j]) (cv::SymmColumnFilter). */
+ * Row pass: ascending-k sum s = k[0]*S[0]; s = fma(k[j], S[j], s) (cv::RowVec_32f / RowFilter);
+ * column pass: symmetric form s = k[c]*S[c]; s = fma(k[c+j], S[c+j]+S[c-j], s) (cv::SymmColumnVec_32f /
+ * SymmColumnFilter).  The multiply-adds are FUSED: OpenCV's universal-intrinsic loops use v_muladd, which is
+ * a hardware fma in every build that dispatches to AVX2/FMA3 or runs on AArch64 NEON (the builds the pip wheels
+ * select on current machines); the SSE2-only baseline would round the product first.  Which one produced the
+ * reference's stored outputs is unknowable (OpenCV version and machine unpinned), so the fused form -- one
+ * rounding per tap, the more accurate of the two -- is the restatement, and the GPU kernels (k_gauss_*) execute
+ * exactly this sequence, so the blurred planes agree bit for bit.
+ * target_clones: the "fma" clone inlines fmaf as vfmadd*, the default clone calls libm's (same result). */
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__) && !defined(CVL_NO_CLONES)
+__attribute__((target_clones("fma", "default")))
+#endif
 void cvl_gaussian_blur_f32(const float *src, float *dst, int h, int w, double sigma)
 {
     int n = cvl_gaussian_ksize_f32(sigma);
@@ -100,7 +110,7 @@ void cvl_gaussian_blur_f32(const float *src, float *dst, int h, int w, double si
         float *t = tmp + (size_t)y * w;
         for (int x = 0; x < w; x++) {
             float acc = k[0] * s[xi[x]];
-            for (int j = 1; j < n; j++) acc += k[j] * s[xi[x + j]];
+            for (int j = 1; j < n; j++) acc = fmaf(k[j], s[xi[x + j]], acc);
             t[x] = acc;
         }
     }
@@ -114,7 +124,7 @@ void cvl_gaussian_blur_f32(const float *src, float *dst, int h, int w, double si
             const float *a = tmp + (size_t)yi[y + r + j] * w;
             const float *b = tmp + (size_t)yi[y + r - j] * w;
             float kj = k[r + j];
-            for (int x = 0; x < w; x++) d[x] += kj * (a[x] + b[x]);
+            for (int x = 0; x < w; x++) d[x] = fmaf(kj, a[x] + b[x], d[x]);
         }
     }
     free(yi); free(xi); free(tmp); free(k);

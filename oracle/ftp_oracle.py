@@ -7,7 +7,9 @@ This is a NumPy restatement of /root/reference/Code/shape_ftp.py `main` steps 8-
 after image loading / alignment) and of the force tail in /root/reference/Code/force_sensor.py.
 NumPy calls (fft2, percentile, median, lstsq) are the same calls the reference makes, so dtype
 promotion follows NumPy exactly as it would for the reference under the NumPy installed here
-(2.2.6).  OpenCV calls are replaced by oracle/cvlite.c (OpenCV is absent and its version unpinned
+(2.2.6) -- with ONE stated exception, the precision of the two FFTs (see FFT_COMPLEX128 below: the
+reference pins no NumPy version and the two NumPy generations transform a float32 array in different
+precisions).  OpenCV calls are replaced by oracle/cvlite.c (OpenCV is absent and its version unpinned
 upstream: "parity unpinned" at the single-stage level, tolerance-checked end to end against the
 stored height_map_bundle.npz goldens).
 
@@ -31,6 +33,16 @@ from typing import Any, Dict, Optional, Tuple
 import numpy as np
 
 from . import cvlite as cv
+
+# Precision of the two FFTs of ftp_complex_demod (shape_ftp.py:867, :953).  The reference calls np.fft.fft2 on a float32
+# array and pins no NumPy version (README.md:63): NumPy < 2.0 computes that transform in complex128, NumPy >= 2.0 in
+# complex64, so the reference's own demodulated field differs between the two by complex64 rounding noise (~1e-7 of the
+# spectrum's scale) -- enough to move pixels that sit on a hard threshold (quality >= p25, :749-753).  The oracle
+# therefore takes the transform both generations approximate: complex128 (True, the default; exactly what the
+# reference computes under NumPy 1.x).  False reproduces NumPy >= 2 (complex64) and is kept for the CPU test that
+# measures how far the two are apart (tests/test_oracle_golden.py::test_fft_precision_modes_agree).  The GPU path
+# accumulates its pruned DFT in float64 with float64 twiddles, i.e. it follows the complex128 form.
+FFT_COMPLEX128 = True
 
 
 # ---------------------------------------------------------------------------------------------
@@ -279,7 +291,7 @@ def ftp_complex_demod(gray_crop_u8, apo, cfg, locked_peak_refined=None):
     hf, wf = iw_fft.shape
     cy, cx = hf // 2, wf // 2
 
-    F = np.fft.fft2(iw_fft)
+    F = np.fft.fft2(iw_fft.astype(np.float64) if FFT_COMPLEX128 else iw_fft)
     F_shift = np.fft.fftshift(F)
     fft_mag = np.abs(F_shift)
 

@@ -48,7 +48,11 @@ def test_global_shift_only_matches_oracle(pkg, photos):
     al = pkg.FtpAligner(photos[0], use_ecc=False, max_batch=1)
     out = al.align(photos[1])
     shift_o, resp_o = A.estimate_global_shift(A.bgr2gray_u8(photos[0]).astype(np.float32), A.bgr2gray_u8(photos[1]).astype(np.float32))
-    assert abs(out["shift"][0, 0] - shift_o[0]) <= 5e-3 and abs(out["shift"][0, 1] - shift_o[1]) <= 5e-3   # float32 FFTs (hipFFT vs pocketfft): measured 2.2e-3
+    # float32 FFTs (hipFFT vs pocketfft) of a WHITENED cross-power spectrum (every bin has unit magnitude, so rounding noise is not
+    # averaged down): the 5x5 centroid moves by up to ~1e-2 px between two float32 transforms (measured 2.2e-3 .. 8.7e-3 as the blur's
+    # rounding changed).  warpAffine quantises the shift to 1/32 px, so what matters downstream is the same quantised shift:
+    assert abs(out["shift"][0, 0] - shift_o[0]) <= 2e-2 and abs(out["shift"][0, 1] - shift_o[1]) <= 2e-2
+    assert np.array_equal(np.rint(np.asarray(out["shift"][0], np.float64) * 32), np.rint(np.asarray(shift_o, np.float64) * 32))
     assert abs(out["response"][0] - resp_o) <= 2e-2 * abs(resp_o)      # sum of a 5x5 window of a noise-dominated whitened correlation: 0.8 % measured
     # same shift -> the warped, cropped, grey-converted window must be the oracle's bit for bit
     M = np.array([[1, 0, np.float32(out["shift"][0, 0])], [0, 1, np.float32(out["shift"][0, 1])]], np.float32)

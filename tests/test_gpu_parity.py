@@ -29,7 +29,7 @@ def _sensor(pkg, cal, n, cfg, max_batch, ref=None, **kw):
     return ref, pkg.FtpSensor(ref, pkg.synth.roi_circle(n), cfg, cal[0], cal[1], cal[2], max_batch=max_batch)
 
 
-def _check_frame(out, b, o, n, exact_masks=True, check_argmin=True, allow_blob_flips=False):
+def _check_frame(out, b, o, n, check_argmin=True):
     """compare GPU outputs of frame b against oracle result dict o"""
     hm = out["height_map_mm"][b].cpu().numpy()
     ref = o["height_map_mm_crop"]
@@ -37,19 +37,10 @@ def _check_frame(out, b, o, n, exact_masks=True, check_argmin=True, allow_blob_f
     assert np.array_equal(np.isnan(hm), np.isnan(ref))
     peak = max(float(np.nanmax(np.abs(ref))), 1e-6)
     diff = np.abs(hm - ref)
-    if allow_blob_flips:
-        # At native size (1.4 Mpx) a handful of pixels sit within float32 rounding of a hard threshold (quality p25,
-        # `depth > 0`): the reliable mask / blob candidates then differ in a few pixels (checked: <= 2e-4 of the frame),
-        # which moves the frontier taper and blob filter locally.  The reference is equally sensitive to its own
-        # rounding there, so: 99.9 % of the pixels must meet the tolerance, the rest 20x the tolerance.
-        bad = np.nan_to_num(diff) > RTOL * peak
-        assert bad.sum() <= 1e-3 * n * n
-        assert float(np.nanmax(diff)) <= 20 * RTOL * peak
-        diff = np.where(bad, 0.0, diff)
     assert float(np.nanmax(diff)) <= RTOL * peak
     rel = out["output_reliable"][b].cpu().numpy().astype(bool)
     mism = int((rel != o["output_reliable_crop"]).sum())
-    assert mism == 0 if exact_masks else mism <= 2e-4 * n * n
+    assert mism == 0
     s = out["scalars"][b].cpu().numpy()
     assert int(s[4]) == o["argmax_depth_index"]                       # arg-max depth index: bit-exact
     v, (ax, ay) = o["argmin_unitless"]
@@ -60,7 +51,7 @@ def _check_frame(out, b, o, n, exact_masks=True, check_argmin=True, allow_blob_f
         assert abs(s[i] - o[key]) <= RTOL * max(abs(o[key]), 1e-9), key
     # the carrier peak is refined in float32 from spectrum magnitudes: equal to ~1 ulp of the peak position
     assert abs(s[5] - o["estimated_grating_period_px"]) <= 1e-5 * s[5] and abs(s[6] - o["mm_per_px"]) <= 1e-5 * s[6]
-    assert abs(int(s[9]) - int(o["reliable"].sum())) <= (0 if exact_masks else 2e-4 * n * n)
+    assert int(s[9]) == int(o["reliable"].sum())
 
 
 @pytest.mark.parametrize("mode", ["scaled", "shipped"])
@@ -73,7 +64,8 @@ def test_full_path_matches_oracle_224(pkg, cal, mode):
     torch.cuda.synchronize()
     info = sensor.reference_info
     rs = O.make_reference_state(ref, *pkg.synth.roi_circle(n), cfg)
-    assert info["peak_refined"] == rs["demod"]["peak_refined"]       # carrier search identical
+    # carrier search: same integer bin; the float64 log-parabolic refinement agrees to the rounding of log() (device vs glibc)
+    assert np.allclose(info["peak_refined"], rs["demod"]["peak_refined"], rtol=0, atol=1e-9)
     assert info["fft_shape"] == rs["demod"]["fft_shape"]
     for b in range(nb):
         o = O.process_frame(frames[b], rs, cfg, *cal, keep_intermediates=True)
@@ -88,9 +80,14 @@ def test_full_path_matches_oracle_224(pkg, cal, mode):
 
 
 def test_stage_intermediates_224(pkg, cal):
+    """Stage by stage.  Planes that feed a hard threshold (Sobel magnitude / intensity -> bad-pixel mask, amplitude product -> Gaussian
+    -> quality >= p25) must equal the oracle's BIT FOR BIT: the demodulation runs in float64 up to the float32 amplitude / phase (as the
+    oracle's complex128 transform) and the Gaussian executes cv's row / symmetric-column sequence with fused multiply-adds (as
+    oracle/cvlite.c).  Continuous planes downstream of the float32 LAPACK lstsq keep a tolerance."""
     n, nb = 224, 2
     cfg = pkg.FtpConfig.scaled(n)
     ref, sensor = _sensor(pkg, cal, n, cfg, nb)
+    sensor._test_set("keep_planes", 1)
     frames = pkg.synth.deformed_batch(n, 40, nb)
     sensor.predict_batch(frames)
     torch.cuda.synchronize()
@@ -100,8 +97,16 @@ def test_stage_intermediates_224(pkg, cal):
     def plane(name, dt=torch.float32):
         return sensor.intermediate(name, nb, dt).cpu().numpy()
 
-    cref = sensor.intermediate("cref", 1, torch.float32).cpu().numpy().reshape(n, n, 2)
-    assert np.abs((cref[..., 0] + 1j * cref[..., 1]) - rs["demod"]["field"]).max() <= 1e-5 * np.abs(rs["demod"]["field"]).max()
+    cref = sensor.intermediate("cref", 1, torch.float64).cpu().numpy().reshape(n, n, 2)
+    assert np.abs((cref[..., 0] + 1j * cref[..., 1]) - rs["demod"]["field"]).max() <= 1e-12 * np.abs(rs["demod"]["field"]).max()
+    roi = rs["roi"]
+
+    def same_bits_in_roi(a, b):
+        """bit-identical inside the ROI; outside it the apodised field is ~1e-7 of its scale inside, so the ~1e-15 (relative to that
+        scale) difference between the two float64 transforms shows as last-bit differences of values nothing ever reads"""
+        return np.array_equal(a[roi], b[roi]) and float(np.abs(a - b).max()) <= 1e-9 * float(np.abs(b).max())
+
+    assert same_bits_in_roi(sensor.intermediate("amp_ref", 1).cpu().numpy().reshape(n, n), rs["demod"]["amp"])
     for b in range(nb):
         o = O.process_frame(frames[b], rs, cfg, *cal, keep_intermediates=True)
         it, sl = o["inter"], slice(b * P, (b + 1) * P)
@@ -110,10 +115,15 @@ def test_stage_intermediates_224(pkg, cal):
         assert plane("thr_hi")[b] == np.float32(di["hi_thr"]) and plane("thr_g")[b] == np.float32(di["g_thr"])
         inp = plane("img")[sl].reshape(n, n)
         assert np.abs(inp - di["img_inpainted"]).max() <= 1e-5 * 255                                   # Telea inpaint
-        fld = plane("field").reshape(nb, n, n, 2)[b]
+        fld = plane("field", torch.float64).reshape(nb, n, n, 2)[b]
         fo = it["demod"]["field"]
-        assert np.abs((fld[..., 0] + 1j * fld[..., 1]) - fo).max() <= 1e-5 * np.abs(fo).max()          # pruned DFT == fft2/ifft2 path
-        assert np.abs(plane("quality")[sl].reshape(n, n) - it["quality"]).max() <= 1e-5 * it["quality"].max()
+        assert np.abs((fld[..., 0] + 1j * fld[..., 1]) - fo).max() <= 1e-12 * np.abs(fo).max()         # pruned DFT == fft2/ifft2 path (complex128)
+        assert np.array_equal(inp, di["img_inpainted"])                                                # ... in OpenCV's summation order: same bits
+        assert same_bits_in_roi(plane("amp")[sl].reshape(n, n), it["demod"]["amp"])                    # |field| -> float32
+        assert same_bits_in_roi(plane("quality")[sl].reshape(n, n), it["quality"])                     # blur(amp_ref * amp_def)
+        wg, wo = plane("wrapped")[sl].reshape(n, n), it["wrapped"]                                     # angle(cdef conj(cref)) -> float32: an
+        assert int((wg != wo)[o["reliable"]].sum()) <= 1e-3 * P and np.abs(wg - wo)[o["reliable"]].max() <= 1e-7   # absolute angle error 1e-15 / |field| vs ulp(angle)
+        assert float(sensor._last_out["scalars"][b, 11]) == np.float32(it["amp_thr"])                 # p25 threshold
         assert np.array_equal(plane("rel0", torch.uint8)[sl].reshape(n, n) != 0, it["thresholded"])
         assert np.array_equal(plane("reliable", torch.uint8)[sl].reshape(n, n) != 0, o["reliable"])   # close, CC, chamfer erode
         uw, uo = plane("unwrapped")[sl].reshape(n, n), it["unwrapped"]
@@ -277,9 +287,9 @@ def test_native_size_1182_as_shipped(pkg, cal):
     rs = O.make_reference_state(ref, *pkg.synth.roi_circle(n), cfg)
     pg, po = sensor.reference_info["peak_refined"], rs["demod"]["peak_refined"]
     assert (round(pg[0]), round(pg[1])) == (round(po[0]), round(po[1]))          # same integer carrier bin
-    assert abs(pg[0] - po[0]) <= 2e-4 and abs(pg[1] - po[1]) <= 2e-4             # float32 log-parabolic refinement, ~1 ulp at 700
+    assert abs(pg[0] - po[0]) <= 1e-9 and abs(pg[1] - po[1]) <= 1e-9             # float64 log-parabolic refinement
     o = O.process_frame(frame, rs, cfg, *cal)
-    _check_frame(out, 0, o, n, exact_masks=False, allow_blob_flips=True)
+    _check_frame(out, 0, o, n)
 
 
 def test_non_square_odd_sizes(pkg, cal):
@@ -302,7 +312,7 @@ def test_non_square_odd_sizes(pkg, cal):
     out = sensor.predict_batch(frames)
     torch.cuda.synchronize()
     rs = O.make_reference_state(ref, *circle, cfg)
-    assert sensor.reference_info["peak_refined"] == rs["demod"]["peak_refined"]
+    assert np.allclose(sensor.reference_info["peak_refined"], rs["demod"]["peak_refined"], rtol=0, atol=1e-9)
     for b in range(2):
         o = O.process_frame(frames[b], rs, cfg, *cal)
         hm = out["height_map_mm"][b].cpu().numpy()
@@ -316,10 +326,10 @@ def test_non_square_odd_sizes(pkg, cal):
 
 
 
-@pytest.mark.parametrize("var,val", [("VISTAF_INPAINT", "seq"), ("VISTAF_INPAINT", "cluster"), ("VISTAF_FLOOD", "hot"), ("VISTAF_FLOOD", "scan")])
+@pytest.mark.parametrize("var,val", [("inpaint_tier", 1), ("inpaint_tier", 0), ("flood_tier", 1), ("flood_tier", 0), ("chamfer_twopass", 1)])
 def test_alternative_kernel_tiers_agree(pkg, cal, var, val):
-    """The fallback / opt-in kernels (whole-frame and cluster-parallel Telea, one-pop and scan floods) stay parity-green: same
-    frames through the default path and through the alternative, compared with each other and with the oracle."""
+    """The fallback / opt-in kernels (whole-frame and cluster-parallel Telea, one-pop and scan floods, two-pass chamfer) stay
+    parity-green: same frames through the default path and through the alternative, compared with each other and with the oracle."""
     n, nb = 224, 6
     cfg = pkg.FtpConfig.scaled(n)
     ref, sensor = _sensor(pkg, cal, n, cfg, nb, config=3)
@@ -328,17 +338,14 @@ def test_alternative_kernel_tiers_agree(pkg, cal, var, val):
     torch.cuda.synchronize()
     hm0 = base["height_map_mm"].cpu().numpy().copy()
     par0 = sensor.intermediate("parent", nb, torch.int32).cpu().numpy().copy()
-    os.environ[var] = val
-    try:
-        alt = sensor.predict_batch(frames)
-        torch.cuda.synchronize()
-        hm1 = alt["height_map_mm"].cpu().numpy().copy()
-        par1 = sensor.intermediate("parent", nb, torch.int32).cpu().numpy().copy()
-        st = alt["status"].cpu().numpy()
-    finally:
-        os.environ.pop(var, None)
+    sensor._test_set(var, val)                                              # csrc/test_hooks.h: per-session, not an environment switch
+    alt = sensor.predict_batch(frames)
+    torch.cuda.synchronize()
+    hm1 = alt["height_map_mm"].cpu().numpy().copy()
+    par1 = sensor.intermediate("parent", nb, torch.int32).cpu().numpy().copy()
+    st = alt["status"].cpu().numpy()
     assert (st == 0).all()
-    if var == "VISTAF_FLOOD":
+    if var != "inpaint_tier":
         assert np.array_equal(par0, par1)                                   # the growth tree is an integer result: identical
         assert np.array_equal(hm0, hm1, equal_nan=True)
     else:
@@ -369,7 +376,7 @@ def test_phase_to_height_constants_variant(pkg, cal):
 def test_inpaint_window_tier_against_sequential_tier_and_oracle_on_many_frames(pkg, cal):
     """The window march executes up to four outside-pass pops per step and a straight-line fill (k_inpaint_win.hip); both must
     leave the pop order of the one-at-a-time march untouched.  48 frames with different hole layouts through the window tier and
-    through the whole-frame sequential tier (`VISTAF_INPAINT=seq`, one pop per step): the inpainted planes must agree to the
+    through the whole-frame sequential tier (test hook `inpaint_tier` = 1, one pop per step): the inpainted planes must agree to the
     float-sum tolerance (the tiers reduce the estimator sums in different orders; a pop out of order moves a filled pixel by far
     more), and a sample of the frames is checked against the oracle's OpenCV-restated Telea."""
     n, nb = 224, 48
@@ -381,14 +388,11 @@ def test_inpaint_window_tier_against_sequential_tier_and_oracle_on_many_frames(p
     torch.cuda.synchronize()
     img0 = sensor.intermediate("img", nb).cpu().numpy().reshape(nb, n, n).copy()
     bad0 = sensor.intermediate("bad1", nb, torch.uint8).cpu().numpy().reshape(nb, n, n).copy()
-    os.environ["VISTAF_INPAINT"] = "seq"
-    try:
-        out = sensor.predict_batch(frames)
-        torch.cuda.synchronize()
-        img1 = sensor.intermediate("img", nb).cpu().numpy().reshape(nb, n, n).copy()
-        assert (out["status"].cpu().numpy() == 0).all()
-    finally:
-        os.environ.pop("VISTAF_INPAINT", None)
+    sensor._test_set("inpaint_tier", 1)
+    out = sensor.predict_batch(frames)
+    torch.cuda.synchronize()
+    img1 = sensor.intermediate("img", nb).cpu().numpy().reshape(nb, n, n).copy()
+    assert (out["status"].cpu().numpy() == 0).all()
     assert bad0.any(axis=(1, 2)).all()                                   # every frame has holes to fill
     assert np.array_equal(img0[bad0 == 0], img1[bad0 == 0])              # known pixels untouched, bit for bit
     assert float(np.abs(img0 - img1).max()) <= 1e-5 * 255
@@ -401,12 +405,9 @@ def test_inpaint_window_tier_against_sequential_tier_and_oracle_on_many_frames(p
 
 
 def test_sixty_four_more_frames_against_oracle(pkg, cal):
-    """Breadth: 64 further synthetic frames (two amplitude scales) end to end against the oracle.  Guards the data-dependent kernels
-    (run-based components, chamfer-ball erosion, exact selection, batched march / flood) against inputs the small tests do not reach.
-    The path thresholds float planes (quality > percentile, depth > eps ...): a pixel that sits on a threshold to within the 1e-7
-    difference between the GPU's and NumPy's transforms flips, and the two-pass detrend spreads that over the map (measured: 2 of 64
-    frames, 2 pixels of the reliable mask, up to 4e-3 of the peak).  So: every frame within a loose bar (masks within 8 pixels, map within
-    1e-2 of the peak, volume within 1e-3, arg-max within the same blob), and at least 9 in 10 within the strict bar of the other tests."""
+    """Breadth: 64 further synthetic frames (two amplitude scales) end to end against the oracle, EVERY frame at the strict bar of the
+    other tests (map within 1e-4 of its peak, masks equal, arg-max index equal).  Guards the data-dependent kernels (run-based
+    components, chamfer-ball erosion, exact selection, batched march / flood) against inputs the small tests do not reach."""
     n, nb = 224, 64
     cfg = pkg.FtpConfig.scaled(n)
     ref, sensor = _sensor(pkg, cal, n, cfg, nb, config=3)
@@ -415,21 +416,9 @@ def test_sixty_four_more_frames_against_oracle(pkg, cal):
     torch.cuda.synchronize()
     rs = O.make_reference_state(ref, *pkg.synth.roi_circle(n), cfg)
     rel = sensor.intermediate("reliable", nb, torch.uint8).cpu().numpy().reshape(nb, n, n) != 0
-    strict = 0
+    qual = sensor.intermediate("quality", nb).cpu().numpy().reshape(nb, n, n)
     for b in range(nb):
-        o = O.process_frame(frames[b], rs, cfg, *cal)
-        assert int(out["status"][b]) == 0
-        hm, r = out["height_map_mm"][b].cpu().numpy(), o["height_map_mm_crop"]
-        s = out["scalars"][b].cpu().numpy()
-        peak = max(float(np.nanmax(np.abs(r))), 1e-6)
-        both = ~(np.isnan(hm) | np.isnan(r))
-        d = float(np.abs(hm[both] - r[both]).max()) / peak
-        dv = abs(s[0] - o["volume_cm3"]) / max(abs(o["volume_cm3"]), 1e-9)
-        flips = int((rel[b] != o["reliable"]).sum())
-        nan_flips = int((np.isnan(hm) != np.isnan(r)).sum())
-        assert flips <= 8 and nan_flips <= 8 and d <= 1e-2 and dv <= 1e-3, (b, flips, nan_flips, d, dv)
-        y0, x0 = divmod(int(s[4]), n)
-        y1, x1 = divmod(int(o["argmax_depth_index"]), n)
-        assert abs(y0 - y1) <= 2 and abs(x0 - x1) <= 2, (b, int(s[4]), o["argmax_depth_index"])
-        strict += int(flips == 0 and nan_flips == 0 and d <= RTOL and dv <= RTOL and int(s[4]) == o["argmax_depth_index"])
-    assert strict >= (9 * nb) // 10, strict
+        o = O.process_frame(frames[b], rs, cfg, *cal, keep_intermediates=True)
+        assert np.array_equal(qual[b][rs["roi"]], o["inter"]["quality"][rs["roi"]]), b   # the plane the reliable mask is thresholded from: same bits
+        assert np.array_equal(rel[b], o["reliable"]), b
+        _check_frame(out, b, o, n)

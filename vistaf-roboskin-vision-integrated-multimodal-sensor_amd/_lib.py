@@ -25,6 +25,7 @@ EXPORTS = [
     "vistaf_ftp_enable_stage_timing", "vistaf_ftp_get_stage_times", "vistaf_ftp_destroy",
     "vistaf_depth_map_to_volume", "vistaf_predict_force_from_volume",
 ]
+TEST_EXPORTS = ["vistaf_ftp_test_set"]   # csrc/test_hooks.h: kernel tier selection / debug planes for the parity tests
 ALIGN_EXPORTS = [            # include/vistaf_align.h
     "vistaf_align_default_config", "vistaf_align_create", "vistaf_align_destroy", "vistaf_align_geometry",
     "vistaf_align_set_reference", "vistaf_align_batch",
@@ -87,7 +88,8 @@ def load():
     lib.vistaf_ftp_destroy.restype = None
     lib.vistaf_depth_map_to_volume.argtypes = [vp, vp, ci, ci, ci, cd, cd, vp, vp]
     lib.vistaf_predict_force_from_volume.argtypes = [ctypes.POINTER(Curve), cd, ctypes.POINTER(cd)]
-    for fn in EXPORTS + ALIGN_EXPORTS:
+    lib.vistaf_ftp_test_set.argtypes = [vp, ctypes.c_char_p, ci]
+    for fn in EXPORTS + ALIGN_EXPORTS + TEST_EXPORTS:
         getattr(lib, fn)
     _lib = lib
     return lib

@@ -14,7 +14,10 @@
 #include "kernels.hpp"
 
 using namespace vf;
+#include "test_hooks.h"
+#ifdef VISTAF_DEBUG
 namespace vf { void telea_debug_dump(); void telea_window_debug_dump(int B); }
+#endif
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -51,18 +54,30 @@ struct vistaf_ftp_handle {
     GKern g_illum, g_pre, g_qual, g_rel, g_unrel;
     RowSpanSE se_bad, se_close, se_contact;
 
-    // reference state
+    // reference state (session mode: one carrier, tables shared by the batch)
     double peak_x = 0, peak_y = 0, kx = 0, ky = 0, period = 0, mm_per_px = 0;
-    int Hf = 0, Wf = 0, ph = 0, pw = 0;
-    float2 *Ex = nullptr, *Ey = nullptr, *Gx = nullptr, *Gy = nullptr, *cref = nullptr;
+    int Hf = 0, Wf = 0, ph = 0, pw = 0, pmax = 0;
+    double2 *Ex = nullptr, *Ey = nullptr, *Gx = nullptr, *Gy = nullptr, *cref = nullptr;
     float *win = nullptr, *amp_ref = nullptr;
+    CarrierGeom *geom = nullptr;                      // [1] session carrier, device
+    // carrier search (full spectrum), allocated on first use for `search_cap` frames
+    double2 *Exf = nullptr, *Eyf = nullptr, *search_tmp = nullptr;
+    double *search_mag = nullptr, *search_peaks = nullptr;
+    int search_cap = 0;
+    // uncached-pair mode (vistaf_ftp_predict_pairs): per-frame carriers, tables and reference fields, allocated on first use
+    CarrierGeom *pgeom = nullptr;
+    double2 *pEx = nullptr, *pEy = nullptr, *pGx = nullptr, *pGy = nullptr, *pcref = nullptr;
+    float *pamp_ref = nullptr;
+    bool pairs_ready = false;
+    Tiers tiers;                                       // kernel tier selection (test hook; defaults = production kernels)
+    bool keep_planes = false;                          // test hook: also write planes that only the parity tests read (float64 field)
 
     // workspace (maxB frames)
     std::map<std::string, std::pair<void *, size_t>> named;   // name -> (ptr, bytes per frame)
     std::vector<void *> allocs;
     float *img, *grad, *tmpf, *blurA, *inorm, *iw, *amp, *prod, *quality, *wrapped, *unwrapped, *phase1, *resid0, *detr, *z0, *mplane,
         *num, *den, *hmap, *dist, *z0f, *snum, *unitless, *depth;
-    float2 *field, *patch;
+    double2 *field, *patch;
     double2 *tmpT;
     uint8_t *bad0, *bad1, *rel0, *rel1, *rel2, *reliable, *contact, *contact_d, *background, *cand, *kept;
     int32_t *labels, *area, *rowdist, *parent;
@@ -195,11 +210,10 @@ void preprocess(vistaf_ftp_handle *hd, const void *frames, int format, int B, hi
             const uint8_t *seq_mask = hd->bad1;
             const int32_t *only = nullptr;
             // default: the frame-window kernel (LDS-resident march), then the whole-frame kernel for the frames it hands back.
-            // VISTAF_INPAINT=cluster: first march every small independent cluster of hole pixels on its own window (pays off when
+            // Tiers::inpaint 0: first march every small independent cluster of hole pixels on its own window (pays off when
             // the hole mask is many separate blobs; the fringe crests of this path form a few large clusters per frame, so it is off
-            // by default); =seq: whole-frame kernel only
-            const char *ev = getenv("VISTAF_INPAINT");          // read on every call: the parity tests switch between the tiers
-            const int mode = (ev && !strcmp(ev, "seq")) ? 1 : (ev && !strcmp(ev, "cluster")) ? 0 : 2;
+            // by default); 1: whole-frame kernel only
+            const int mode = hd->tiers.inpaint;
             if (mode == 0 && inpaint_clusters_supported(range)) {
                 uint8_t *bad_big = nullptr;
                 launch_inpaint_clusters(hd->img, hd->bad1, range, hd->inpaint_cl_scratch, &bad_big, B, h, w, st);
@@ -219,56 +233,14 @@ void preprocess(vistaf_ftp_handle *hd, const void *frames, int format, int B, hi
     launch_select(hd->iw, hd->valid, 0, nullptr, false, hd->req_med, 1, hd->mu, nullptr, B, P, st);
 }
 
-void build_pruned_twiddles(vistaf_ftp_handle *hd, int x0, int y0, double dpx, double dpy, std::vector<float2> &Ex, std::vector<float2> &Ey,
-                           std::vector<float2> &Gx, std::vector<float2> &Gy, std::vector<float> &win)
+// np.hanning(ph)[:,None] * np.hanning(pw)[None,:] in float32 (shape_ftp.py:800-807); np.hanning(M) = 0.5 + 0.5*cos(pi*n/(M-1)), n = 1-M, 3-M, ...
+std::vector<float> hann_patch(int ph, int pw)
 {
-    const double PI2 = 6.283185307179586476925286766559;
-    int h = hd->h, w = hd->w, pad = hd->cfg.fft_pad_px, Hf = hd->Hf, Wf = hd->Wf, ph = hd->ph, pw = hd->pw;
-    int cxs = Wf / 2, cys = Hf / 2;
-    std::vector<double> tcx(Wf), tsx(Wf), tcy(Hf), tsy(Hf);
-    for (int m = 0; m < Wf; m++) { tcx[m] = std::cos(PI2 * m / Wf); tsx[m] = -std::sin(PI2 * m / Wf); }
-    for (int m = 0; m < Hf; m++) { tcy[m] = std::cos(PI2 * m / Hf); tsy[m] = -std::sin(PI2 * m / Hf); }
-    std::vector<double> er((size_t)w * pw, 0.0), ei((size_t)w * pw, 0.0);
-    for (int X = 0; X < Wf; X++) {
-        int xs = reflect_edge(X - pad, w);
-        for (int c = 0; c < pw; c++) {
-            long f = ((long)(x0 + c - cxs) % Wf + Wf) % Wf;
-            int m = (int)((f * X) % Wf);
-            er[(size_t)xs * pw + c] += tcx[m]; ei[(size_t)xs * pw + c] += tsx[m];
-        }
-    }
-    Ex.resize((size_t)w * pw);
-    for (size_t i = 0; i < Ex.size(); i++) Ex[i] = make_float2((float)er[i], (float)ei[i]);
-    std::vector<double> fr((size_t)ph * h, 0.0), fi((size_t)ph * h, 0.0);
-    for (int Y = 0; Y < Hf; Y++) {
-        int ys = reflect_edge(Y - pad, h);
-        for (int a = 0; a < ph; a++) {
-            long f = ((long)(y0 + a - cys) % Hf + Hf) % Hf;
-            int m = (int)((f * Y) % Hf);
-            fr[(size_t)a * h + ys] += tcy[m]; fi[(size_t)a * h + ys] += tsy[m];
-        }
-    }
-    Ey.resize((size_t)ph * h);
-    for (size_t i = 0; i < Ey.size(); i++) Ey[i] = make_float2((float)fr[i], (float)fi[i]);
-    // inverse: patch element (a,c) sits at frequency (a - ph/2, c - pw/2) after re-centring (shape_ftp.py:945-948)
-    Gx.resize((size_t)pw * w);
-    for (int c = 0; c < pw; c++)
-        for (int x = 0; x < w; x++) {
-            double ang = PI2 * ((double)(c - pw / 2) - dpx) * (double)(x + pad) / (double)Wf;
-            Gx[(size_t)c * w + x] = make_float2((float)std::cos(ang), (float)std::sin(ang));
-        }
-    Gy.resize((size_t)h * ph);
-    double scale = 1.0 / ((double)Hf * (double)Wf);
-    for (int y = 0; y < h; y++)
-        for (int a = 0; a < ph; a++) {
-            double ang = PI2 * ((double)(a - ph / 2) - dpy) * (double)(y + pad) / (double)Hf;
-            Gy[(size_t)y * ph + a] = make_float2((float)(std::cos(ang) * scale), (float)(std::sin(ang) * scale));
-        }
-    // np.hanning(ph)[:,None] * np.hanning(pw)[None,:] in float32 (shape_ftp.py:800-807)
-    auto hann = [](int M, int n) -> float { return M == 1 ? 1.0f : (float)(0.5 - 0.5 * std::cos(6.283185307179586476925286766559 * n / (M - 1))); };
-    win.resize((size_t)ph * pw);
+    auto hann = [](int M, int i) -> float { return M == 1 ? 1.0f : (float)(0.5 + 0.5 * std::cos(3.14159265358979323846 * (double)(1 - M + 2 * i) / (double)(M - 1))); };
+    std::vector<float> win((size_t)ph * pw);
     for (int a = 0; a < ph; a++)
         for (int c = 0; c < pw; c++) win[(size_t)a * pw + c] = hann(ph, a) * hann(pw, c);
+    return win;
 }
 
 template <typename T>
@@ -374,7 +346,7 @@ int vistaf_ftp_create(const vistaf_ftp_config *cfg, int h, int w, int cx, int cy
     PLANE(float, amp); PLANE(float, prod); PLANE(float, quality); PLANE(float, wrapped); PLANE(float, unwrapped); PLANE(float, phase1);
     PLANE(float, resid0); PLANE(float, detr); PLANE(float, z0); PLANE(float, mplane); PLANE(float, num); PLANE(float, den);
     PLANE(float, hmap); PLANE(float, dist); PLANE(float, z0f); PLANE(float, snum); PLANE(float, unitless); PLANE(float, depth);
-    PLANE(float2, field);
+    PLANE(double2, field);
     PLANE(uint8_t, bad0); PLANE(uint8_t, bad1); PLANE(uint8_t, rel0); PLANE(uint8_t, rel1); PLANE(uint8_t, rel2); PLANE(uint8_t, reliable);
     PLANE(uint8_t, contact); PLANE(uint8_t, contact_d); PLANE(uint8_t, background); PLANE(uint8_t, cand); PLANE(uint8_t, kept);
     PLANE(int32_t, labels); PLANE(int32_t, area); PLANE(int32_t, rowdist); PLANE(int32_t, parent);
@@ -389,8 +361,14 @@ int vistaf_ftp_create(const vistaf_ftp_config *cfg, int h, int w, int cx, int cy
         TRY(dalloc(hd, (uint8_t **)&p, unwrap_scratch_bytes_per_frame(h, w) * max_batch + 1024)); hd->unwrap_scratch = p;
     }
     int pmax = 2 * bwp + 1;
-    TRY(dalloc(hd, &hd->patch, (size_t)max_batch * pmax * pmax, "patch", (size_t)pmax * pmax * sizeof(float2)));
+    hd->pmax = pmax;
+    TRY(dalloc(hd, &hd->patch, (size_t)max_batch * pmax * pmax, "patch", (size_t)pmax * pmax * sizeof(double2)));
     TRY(dalloc(hd, &hd->tmpT, (size_t)max_batch * (size_t)std::max(h, w) * pmax));
+    TRY(dalloc(hd, &hd->Ex, (size_t)w * pmax)); TRY(dalloc(hd, &hd->Gx, (size_t)w * pmax));
+    TRY(dalloc(hd, &hd->Ey, (size_t)h * pmax)); TRY(dalloc(hd, &hd->Gy, (size_t)h * pmax));
+    TRY(dalloc(hd, &hd->win, (size_t)pmax * pmax)); TRY(dalloc(hd, &hd->geom, 1));
+    TRY(dalloc(hd, &hd->cref, (size_t)P)); TRY(dalloc(hd, &hd->amp_ref, (size_t)P));
+    hd->named["cref"] = {hd->cref, 0}; hd->named["amp_ref"] = {hd->amp_ref, 0};
     size_t mb = max_batch;
     TRY(dalloc(hd, &hd->thr_hi, mb)); TRY(dalloc(hd, &hd->thr_g, mb)); TRY(dalloc(hd, &hd->mu, mb)); TRY(dalloc(hd, &hd->amp_thr, mb));
     TRY(dalloc(hd, &hd->thr3, mb * 3)); TRY(dalloc(hd, &hd->thr_used, mb)); TRY(dalloc(hd, &hd->bg_med, mb));
@@ -428,6 +406,32 @@ int vistaf_ftp_create(const vistaf_ftp_config *cfg, int h, int w, int cx, int cy
     return 0;
 }
 
+// carrier search + tables + demodulation of nb reference frames that preprocess() has left in hd->iw / hd->mu (shape_ftp.py:867-961).
+// Asynchronous; geometry lands in geom_dev[0..nb).  ph / pw: patch size the DFT launches use (session mode: read back from the geometry
+// between the two halves; pair mode: the full 2*bw+1 square, frames whose patch is clipped by the spectrum border are refused).
+static int reference_search(vistaf_ftp_handle *hd, int nb, CarrierGeom *geom_dev, hipStream_t st)
+{
+    const vistaf_ftp_config &c = hd->cfg;
+    const int h = hd->h, w = hd->w, Hf = hd->Hf, Wf = hd->Wf, pad = std::max(0, c.fft_pad_px);
+    if (hd->search_cap < nb) {
+        int rc;
+        if (!hd->Exf) {
+            if ((rc = dalloc(hd, &hd->Exf, (size_t)w * Wf)) || (rc = dalloc(hd, &hd->Eyf, (size_t)Hf * h))) return rc;
+            launch_build_full_tables(hd->Exf, hd->Eyf, h, w, pad, Hf, Wf, st);
+        }
+        // (a smaller earlier set stays owned by the handle until destroy; this only grows when pair mode follows session mode)
+        if ((rc = dalloc(hd, &hd->search_tmp, (size_t)nb * h * Wf)) || (rc = dalloc(hd, &hd->search_mag, (size_t)nb * Hf * Wf)) ||
+            (rc = dalloc(hd, &hd->search_peaks, (size_t)nb * 192)))
+            return rc;
+        hd->search_cap = nb;
+    }
+    const int npk = std::min(std::max(1, c.n_fft_peaks), 64);
+    launch_dft_full_mag(hd->iw, hd->mu, hd->Exf, hd->Eyf, hd->search_tmp, hd->search_mag, nb, h, w, Hf, Wf, st);
+    launch_top_peaks(hd->search_mag, nb, Hf, Wf, c.dc_exclusion, npk, hd->search_peaks, st);
+    launch_carrier_choose(hd->search_peaks, npk, hd->search_mag, Hf, Wf, std::max(3, c.patch_half_width_bins), c.peak_max_dy_from_center, geom_dev, nb, st);
+    return 0;
+}
+
 int vistaf_ftp_set_reference(vistaf_ftp_handle *hd, const void *d_ref, int format, void *stream)
 {
     if (!hd || !d_ref) return fail(VISTAF_E_INVALID, "null argument");
@@ -435,103 +439,32 @@ int vistaf_ftp_set_reference(vistaf_ftp_handle *hd, const void *d_ref, int forma
     hipStream_t st = (hipStream_t)stream;
     const vistaf_ftp_config &c = hd->cfg;
     int h = hd->h, w = hd->w, P = hd->P, Hf = hd->Hf, Wf = hd->Wf, pad = std::max(0, c.fft_pad_px);
+    hd->have_ref = false;
     HIPCHK(hipMemsetAsync(hd->status, 0, sizeof(int32_t) * hd->maxB, st));
     preprocess(hd, d_ref, format, 1, st, false);
-    // ---- full spectrum magnitude + top peaks (shape_ftp.py:867-905)
-    const double PI2 = 6.283185307179586476925286766559;
-    std::vector<double> tcx(Wf), tsx(Wf), tcy(Hf), tsy(Hf);
-    for (int m = 0; m < Wf; m++) { tcx[m] = std::cos(PI2 * m / Wf); tsx[m] = -std::sin(PI2 * m / Wf); }
-    for (int m = 0; m < Hf; m++) { tcy[m] = std::cos(PI2 * m / Hf); tsy[m] = -std::sin(PI2 * m / Hf); }
-    std::vector<float2> exf((size_t)w * Wf), eyf((size_t)Hf * h);
+    int rc = reference_search(hd, 1, hd->geom, st);
+    if (rc) return rc;
+    CarrierGeom g;
+    HIPCHK(hipMemcpyAsync(&g, hd->geom, sizeof(g), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (!g.ok) return fail(VISTAF_E_NOCARRIER, "no carrier peak in the reference spectrum");
+    hd->peak_x = g.peak_x; hd->peak_y = g.peak_y; hd->kx = g.kx; hd->ky = g.ky;
+    hd->ph = g.ph; hd->pw = g.pw;
     {
-        std::vector<double> er((size_t)w * Wf, 0.0), ei((size_t)w * Wf, 0.0);
-        for (int X = 0; X < Wf; X++) {
-            int xs = reflect_edge(X - pad, w);
-            for (int f = 0; f < Wf; f++) { int m = (int)(((long)f * X) % Wf); er[(size_t)xs * Wf + f] += tcx[m]; ei[(size_t)xs * Wf + f] += tsx[m]; }
-        }
-        for (size_t i = 0; i < exf.size(); i++) exf[i] = make_float2((float)er[i], (float)ei[i]);
-        std::vector<double> fr((size_t)Hf * h, 0.0), fi((size_t)Hf * h, 0.0);
-        for (int Y = 0; Y < Hf; Y++) {
-            int ys = reflect_edge(Y - pad, h);
-            for (int f = 0; f < Hf; f++) { int m = (int)(((long)f * Y) % Hf); fr[(size_t)f * h + ys] += tcy[m]; fi[(size_t)f * h + ys] += tsy[m]; }
-        }
-        for (size_t i = 0; i < eyf.size(); i++) eyf[i] = make_float2((float)fr[i], (float)fi[i]);
+        std::vector<float> win = hann_patch(g.ph, g.pw);
+        HIPCHK(hipMemcpyAsync(hd->win, win.data(), win.size() * sizeof(float), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));         // `win` is a host temporary
     }
-    float2 *d_ex = nullptr, *d_ey = nullptr;
-    double2 *d_tmp = nullptr;
-    float *d_mag = nullptr, *d_peaks = nullptr;
-    HIPCHK(hipMalloc((void **)&d_ex, exf.size() * sizeof(float2)));
-    HIPCHK(hipMalloc((void **)&d_ey, eyf.size() * sizeof(float2)));
-    HIPCHK(hipMalloc((void **)&d_tmp, (size_t)h * Wf * sizeof(double2)));
-    HIPCHK(hipMalloc((void **)&d_mag, (size_t)Hf * Wf * sizeof(float)));
-    int npk = std::min(std::max(1, c.n_fft_peaks), 64);
-    HIPCHK(hipMalloc((void **)&d_peaks, 3 * 64 * sizeof(float)));
-    HIPCHK(hipMemcpyAsync(d_ex, exf.data(), exf.size() * sizeof(float2), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_ey, eyf.data(), eyf.size() * sizeof(float2), hipMemcpyHostToDevice, st));
-    launch_dft_full_mag(hd->iw, hd->mu, d_ex, d_ey, (float2 *)d_tmp, d_mag, h, w, Hf, Wf, c.dc_exclusion, st);
-    launch_top_peaks(d_mag, Hf, Wf, c.dc_exclusion, npk, d_peaks, st);
-    std::vector<float> pk(3 * npk);
-    HIPCHK(hipMemcpyAsync(pk.data(), d_peaks, pk.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+    launch_build_tables(hd->geom, 0, hd->Ex, hd->Ey, hd->Gx, hd->Gy, 0, 0, 1, h, w, pad, Hf, Wf, hd->pmax, st);
+    launch_dft_forward(hd->iw, hd->mu, hd->Ex, hd->Ey, 0, 0, hd->win, hd->tmpT, hd->patch, hd->pmax * hd->pmax, 1, h, w, hd->ph, hd->pw, st);
+    launch_dft_inverse(hd->patch, hd->pmax * hd->pmax, hd->Gx, hd->Gy, 0, 0, hd->tmpT, hd->cref, hd->amp_ref, nullptr, nullptr, 0, nullptr, nullptr,
+                       1, h, w, hd->ph, hd->pw, st);
     HIPCHK(hipStreamSynchronize(st));
-    // choose_carrier_peak (shape_ftp.py:444-463): right half plane, near the centre row, largest magnitude
-    int cys = Hf / 2, cxs = Wf / 2;
-    std::vector<int> cand(npk);
-    for (int i = 0; i < npk; i++) cand[i] = i;
-    auto filt = [&](auto pred) { std::vector<int> o; for (int i : cand) if (pred(i)) o.push_back(i); if (!o.empty()) cand = o; };
-    filt([&](int i) { return pk[3 * i] > (float)cxs; });
-    int max_dy = (int)(c.peak_max_dy_from_center * Hf);
-    filt([&](int i) { return std::abs((int)pk[3 * i + 1] - cys) <= max_dy; });
-    int best = cand[0];
-    for (int i : cand) if (pk[3 * i + 2] > pk[3 * best + 2]) best = i;
-    int px = (int)pk[3 * best], py = (int)pk[3 * best + 1];
-    if (!(pk[3 * best + 2] > 0.f)) {
-        hipFree(d_ex); hipFree(d_ey); hipFree(d_tmp); hipFree(d_mag); hipFree(d_peaks);
-        return fail(VISTAF_E_NOCARRIER, "no carrier peak in the reference spectrum");
-    }
-    // refine_peak_parabolic_log (shape_ftp.py:473-483), float32 arithmetic as NumPy scalars give
-    double pxf = px, pyf = py;
-    if (px > 0 && px < Wf - 1 && py > 0 && py < Hf - 1) {
-        float m[5];
-        size_t offs[5] = {(size_t)py * Wf + px - 1, (size_t)py * Wf + px, (size_t)py * Wf + px + 1, (size_t)(py - 1) * Wf + px, (size_t)(py + 1) * Wf + px};
-        for (int i = 0; i < 5; i++) HIPCHK(hipMemcpy(&m[i], d_mag + offs[i], sizeof(float), hipMemcpyDeviceToHost));
-        auto lg = [](float v) { return std::log(v + 1e-12f); };
-        auto par = [](float fm1, float f0, float fp1) -> float {
-            float den = (fm1 - 2.0f * f0) + fp1;
-            if (std::fabs(den) < 1e-12f) return 0.0f;
-            return 0.5f * (fm1 - fp1) / den;
-        };
-        float dx = par(lg(m[0]), lg(m[1]), lg(m[2])), dy = par(lg(m[3]), lg(m[1]), lg(m[4]));
-        pxf = (double)((float)px + dx); pyf = (double)((float)py + dy);
-    }
-    hipFree(d_ex); hipFree(d_ey); hipFree(d_tmp); hipFree(d_mag); hipFree(d_peaks);
-    hd->peak_x = pxf; hd->peak_y = pyf;
-    hd->kx = pxf - cxs; hd->ky = pyf - cys;
-    // patch geometry (shape_ftp.py:930-948)
-    int px_i = (int)std::nearbyint(pxf), py_i = (int)std::nearbyint(pyf);
-    int bw = std::max(3, c.patch_half_width_bins);
-    int x0 = std::max(0, px_i - bw), x1 = std::min(Wf, px_i + bw + 1), y0 = std::max(0, py_i - bw), y1 = std::min(Hf, py_i + bw + 1);
-    hd->ph = y1 - y0; hd->pw = x1 - x0;
-    if (hd->ph < 1 || hd->pw < 1) return fail(VISTAF_E_NOCARRIER, "carrier patch is empty");
-    double dpx = pxf - px_i, dpy = pyf - py_i;
-    if (!(std::fabs(dpx) > 1e-6 || std::fabs(dpy) > 1e-6)) { dpx = 0; dpy = 0; }
-    std::vector<float2> Ex, Ey, Gx, Gy;
-    std::vector<float> win;
-    build_pruned_twiddles(hd, x0, y0, dpx, dpy, Ex, Ey, Gx, Gy, win);
-    int rc;
-    if ((rc = upload(hd, &hd->Ex, Ex)) || (rc = upload(hd, &hd->Ey, Ey)) || (rc = upload(hd, &hd->Gx, Gx)) || (rc = upload(hd, &hd->Gy, Gy)) ||
-        (rc = upload(hd, &hd->win, win)))
-        return rc;
-    if (!hd->cref) { if ((rc = dalloc(hd, &hd->cref, (size_t)P)) || (rc = dalloc(hd, &hd->amp_ref, (size_t)P))) return rc; }
-    launch_dft_forward(hd->iw, hd->mu, hd->Ex, hd->Ey, hd->win, (float2 *)hd->tmpT, hd->patch, 1, h, w, hd->ph, hd->pw, st);
-    launch_dft_inverse(hd->patch, hd->Gx, hd->Gy, (float2 *)hd->tmpT, hd->field, hd->amp, 1, h, w, hd->ph, hd->pw, st);
-    HIPCHK(hipMemcpyAsync(hd->cref, hd->field, (size_t)P * sizeof(float2), hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipMemcpyAsync(hd->amp_ref, hd->amp, (size_t)P * sizeof(float), hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));
-    hd->named["cref"] = {hd->cref, 0}; hd->named["amp_ref"] = {hd->amp_ref, 0};
     // period estimate (shape_ftp.py:2015-2027) and scale (force_sensor.py:173-187); carrier is locked so k_def == k_ref
-    hd->period = std::fabs(hd->kx) > 1e-9 ? (double)Wf / std::fabs(hd->kx) : 0.0;
+    hd->period = g.period;
     hd->mm_per_px = hd->period > 1e-12 ? c.grating_pitch_mm / hd->period : 0.0;
     hd->have_ref = true;
+    (void)P;
     return 0;
 }
 
@@ -562,9 +495,9 @@ int vistaf_ftp_predict_batch(vistaf_ftp_handle *hd, const void *d_frames, int fo
 
     // ---- demodulation, carrier locked to the reference (shape_ftp.py:1643-1653, :1681-1689)
     if (timed) hipEventRecord(hd->ev[ST_DEMOD], st);
-    launch_dft_forward(hd->iw, hd->mu, hd->Ex, hd->Ey, hd->win, (float2 *)hd->tmpT, hd->patch, B, h, w, hd->ph, hd->pw, st);
-    launch_dft_inverse(hd->patch, hd->Gx, hd->Gy, (float2 *)hd->tmpT, hd->field, hd->amp, B, h, w, hd->ph, hd->pw, st);
-    launch_phase_diff(hd->field, hd->cref, hd->amp, hd->amp_ref, hd->prod, hd->wrapped, B, P, st);
+    launch_dft_forward(hd->iw, hd->mu, hd->Ex, hd->Ey, 0, 0, hd->win, hd->tmpT, hd->patch, hd->pmax * hd->pmax, B, h, w, hd->ph, hd->pw, st);
+    launch_dft_inverse(hd->patch, hd->pmax * hd->pmax, hd->Gx, hd->Gy, 0, 0, hd->tmpT, hd->keep_planes ? hd->field : nullptr, hd->amp, hd->cref,
+                       hd->amp_ref, 0, hd->prod, hd->wrapped, B, h, w, hd->ph, hd->pw, st);
 
     // ---- reliable mask (shape_ftp.py:739-775)
     if (timed) hipEventRecord(hd->ev[ST_RELIABLE], st);
@@ -600,7 +533,7 @@ int vistaf_ftp_predict_batch(vistaf_ftp_handle *hd, const void *d_frames, int fo
         if (chamfer_ball((float)c.reliable_edge_margin_px, &ball))
             launch_morph(hd->rel2, hd->reliable, B, h, w, ball, false, nullptr, nullptr, st, hd->morph_pre);
         else {
-            launch_chamfer(hd->rel2, false, hd->rowdist, hd->dist, B, h, w, c.reliable_edge_margin_px + 1, st);
+            launch_chamfer(hd->rel2, false, hd->rowdist, hd->dist, B, h, w, c.reliable_edge_margin_px + 1, st, hd->tiers.chamfer_twopass != 0);
             launch_erode_by_dist(hd->dist, hd->rel2, (float)c.reliable_edge_margin_px, hd->reliable, B, P, st);
         }
     } else HIPCHK(hipMemcpyAsync(hd->reliable, hd->rel2, (size_t)B * P, hipMemcpyDeviceToDevice, st));
@@ -610,7 +543,7 @@ int vistaf_ftp_predict_batch(vistaf_ftp_handle *hd, const void *d_frames, int fo
     // ---- unwrap (shape_ftp.py:1702)
     if (timed) hipEventRecord(hd->ev[ST_UNWRAP_RANK], st);
     launch_unwrap(hd->wrapped, qual, hd->reliable, hd->unwrapped, hd->parent, hd->unwrap_scratch, hd->status, B, h, w, st,
-                  timed ? hd->ev[ST_UNWRAP_TREE] : nullptr, timed ? hd->ev[ST_UNWRAP] : nullptr);
+                  timed ? hd->ev[ST_UNWRAP_TREE] : nullptr, timed ? hd->ev[ST_UNWRAP] : nullptr, hd->tiers.flood);
 
     // ---- plane removal + two-pass detrend (shape_ftp.py:1706, :1716-1751)
     if (timed) hipEventRecord(hd->ev[ST_DETREND], st);
@@ -660,7 +593,7 @@ int vistaf_ftp_predict_batch(vistaf_ftp_handle *hd, const void *d_frames, int fo
     float band = (float)c.frontier_zero_band_px;
     // both distance transforms of the reliable mask (to its outside for the taper, to its inside for the final blend) in one launch; the
     // second one lands in planes that are idle at this point (`area` as the integer temporary, `depth` -- written by to_mm below)
-    if (use_band) launch_chamfer_pair(hd->reliable, hd->rowdist, hd->dist, hd->area, hd->depth, B, h, w, c.frontier_zero_band_px + 2, st);
+    if (use_band) launch_chamfer_pair(hd->reliable, hd->rowdist, hd->dist, hd->area, hd->depth, B, h, w, c.frontier_zero_band_px + 2, st, hd->tiers.chamfer_twopass != 0);
     else HIPCHK(hipMemsetAsync(hd->dist, 0x7f, (size_t)B * P * sizeof(float), st));   // huge distance: taper weight 1
     launch_frontier_compose(hd->hmap, hd->reliable, hd->roi, hd->dist, use_band ? band : 1.0f, hd->z0f, hd->status, B, P, st);
     if (hd->g_unrel.k) blur(hd, hd->z0f, hd->snum, hd->g_unrel, B, st);
@@ -688,7 +621,9 @@ int vistaf_ftp_predict_batch(vistaf_ftp_handle *hd, const void *d_frames, int fo
         hipEventSynchronize(hd->ev[ST_COUNT]);
         for (int i = 0; i < ST_COUNT; i++) hipEventElapsedTime(&hd->stage_ms[i], hd->ev[i], hd->ev[i + 1]);
     }
+#ifdef VISTAF_DEBUG
     if (getenv("VISTAF_TELEA_DBG")) { hipStreamSynchronize(st); telea_debug_dump(); telea_window_debug_dump(B); }
+#endif
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VISTAF_E_HIP, std::string("launch: ") + hipGetErrorString(e));
     return 0;
@@ -700,7 +635,7 @@ int vistaf_ftp_get_intermediate(vistaf_ftp_handle *hd, const char *name, void *d
     auto it = hd->named.find(name);
     if (it == hd->named.end()) return fail(VISTAF_E_INVALID, std::string("unknown intermediate: ") + name);
     size_t per = it->second.second;
-    size_t total = per ? per * (size_t)batch : (std::string(name) == "cref" ? (size_t)hd->P * sizeof(float2) : std::string(name) == "amp_ref" ? (size_t)hd->P * sizeof(float) : (size_t)hd->P);
+    size_t total = per ? per * (size_t)batch : (std::string(name) == "cref" ? (size_t)hd->P * sizeof(double2) : std::string(name) == "amp_ref" ? (size_t)hd->P * sizeof(float) : (size_t)hd->P);
     if (bytes_per_frame) *bytes_per_frame = per ? per : total;
     if (d_dst) HIPCHK(hipMemcpyAsync(d_dst, it->second.first, total, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return 0;
@@ -718,6 +653,19 @@ int vistaf_ftp_get_stage_times(vistaf_ftp_handle *hd, float *ms_out, int n)
 {
     if (!hd || !ms_out) return fail(VISTAF_E_INVALID, "null argument");
     for (int i = 0; i < n && i < ST_COUNT; i++) ms_out[i] = hd->stage_ms[i];
+    return 0;
+}
+
+// csrc/test_hooks.h (not part of the public header): kernel tier selection and debug planes for the parity tests
+int vistaf_ftp_test_set(vistaf_ftp_handle *hd, const char *name, int value)
+{
+    if (!hd || !name) return fail(VISTAF_E_INVALID, "null argument");
+    const std::string n(name);
+    if (n == "inpaint_tier" && value >= 0 && value <= 2) hd->tiers.inpaint = value;
+    else if (n == "flood_tier" && value >= 0 && value <= 2) hd->tiers.flood = value;
+    else if (n == "chamfer_twopass") hd->tiers.chamfer_twopass = value != 0;
+    else if (n == "keep_planes") hd->keep_planes = value != 0;
+    else return fail(VISTAF_E_INVALID, "unknown test hook or value: " + n);
     return 0;
 }
 

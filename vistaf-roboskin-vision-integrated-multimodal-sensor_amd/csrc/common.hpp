@@ -129,6 +129,18 @@ __device__ inline unsigned long long block_min_u64(unsigned long long v, unsigne
     return r;
 }
 
+// Dynamic-LDS limit of a kernel above the 64 KB default: the attribute is per device, and one process may hold sessions on several
+// GPUs, so "already set" is tracked per device ordinal.
+struct DynLdsOnce { bool done[64] = {}; };
+inline void ensure_dyn_lds(DynLdsOnce &o, const void *fn, int bytes)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+    if (dev >= 0 && dev < 64 && o.done[dev]) return;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (dev >= 0 && dev < 64) o.done[dev] = true;
+}
+
 // calibration curve (shape_ftp.py:682-700 / force_sensor.py:129-167), double arithmetic
 struct Curve { int type; double a, b, c; };
 __host__ __device__ inline double curve_eval(const Curve &cv, double v)

@@ -358,76 +358,72 @@ __global__ __launch_bounds__(256) void k_gauss_rows(const float *__restrict__ sr
     }
 }
 
-// Column pass: each thread produces GC_R consecutive rows of one column (sliding window in registers),
-// lanes run along x so every tap is a coalesced row read.
+// Column pass: cv::SymmColumnFilter's symmetric form, s = k[r]*S[y]; s = fma(k[r+j], S[y+j] + S[y-j], s) for j = 1..r (the order the
+// oracle restates, oracle/cvlite.c cvl_gaussian_blur_f32: same operations in the same order, so the same bits).  Each thread produces
+// GC_R consecutive rows of one column; lanes run along x so every row read is coalesced.  The two source rows a step needs for its GC_R
+// outputs are the previous step's shifted by one row, so a step costs two new reads (register windows `up` / `dn`).
 constexpr int GC_R = 8;
 
+template <class Load>
+__device__ inline void gauss_col_symm(Load ld, const float *__restrict__ kern, int r, float (&acc)[GC_R])
+{
+    // ld(i): source value i rows below the centre of output 0 (i in [-r, GC_R - 1 + r])
+    float up[GC_R], dn[GC_R];
+    const float kc = kern[r];
+#pragma unroll
+    for (int o = 0; o < GC_R; o++) { const float v = ld(o); acc[o] = __fmul_rn(kc, v); up[o] = v; dn[o] = v; }
+    for (int j = 1; j <= r; j++) {
+        const float nu = ld(GC_R - 1 + j), nd = ld(-j);
+#pragma unroll
+        for (int o = 0; o < GC_R - 1; o++) up[o] = up[o + 1];
+        up[GC_R - 1] = nu;
+#pragma unroll
+        for (int o = GC_R - 1; o > 0; o--) dn[o] = dn[o - 1];
+        dn[0] = nd;
+        const float kj = kern[r + j];
+#pragma unroll
+        for (int o = 0; o < GC_R; o++) acc[o] = fmaf(kj, __fadd_rn(up[o], dn[o]), acc[o]);
+    }
+}
+
+// global-memory form (kernels too long for the LDS tile)
 __global__ __launch_bounds__(256) void k_gauss_cols(const float *__restrict__ src, float *__restrict__ dst,
                                                     const float *__restrict__ kern, int ksize, int h, int w)
 {
-    __shared__ float kk[GB_MAXK];
-    for (int i = threadIdx.x; i < ksize; i += 256) kk[i] = kern[i];
-    __syncthreads();
-    int r = ksize / 2;
-    int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * GC_R;
-    size_t b = blockIdx.z;
+    const int r = ksize / 2;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * GC_R;
+    const size_t b = blockIdx.z;
     if (x >= w || y0 >= h) return;
     const float *s = src + b * (size_t)h * w;
     float acc[GC_R];
-#pragma unroll
-    for (int o = 0; o < GC_R; o++) acc[o] = 0.f;
-    for (int j = 0; j < ksize + GC_R - 1; j++) {
-        float v = s[(size_t)reflect101(y0 + j - r, h) * w + x];
-#pragma unroll
-        for (int o = 0; o < GC_R; o++) {
-            int t = j - o;
-            if (t >= 0 && t < ksize) acc[o] = fmaf(kk[t], v, acc[o]);
-        }
-    }
+    gauss_col_symm([&](int i) { return s[(size_t)reflect101(y0 + i, h) * w + x]; }, kern, r, acc);
 #pragma unroll
     for (int o = 0; o < GC_R; o++)
         if (y0 + o < h) dst[b * (size_t)h * w + (size_t)(y0 + o) * w + x] = acc[o];
 }
 
-// Column pass through LDS: the block's 64 columns x (32 + ksize - 1) source rows are staged with ONE round of independent coalesced
-// loads (the register-window kernel above walks its taps with a dependent load per row: ~ksize L2 round trips per thread), then every
-// thread slides over its 8 output rows.  Same taps in the same order as k_gauss_cols: same bits.
+// Column pass through LDS: the block's 64 columns x (32 + 2r) source rows are staged with ONE round of independent coalesced loads
+// (the global form walks its taps with dependent loads), then every thread runs the symmetric sum over its 8 output rows.
 __global__ __launch_bounds__(256) void k_gauss_cols_lds(const float *__restrict__ src, float *__restrict__ dst,
                                                         const float *__restrict__ kern, int ksize, int h, int w)
 {
     extern __shared__ float lds[];
-    float *kk = lds;                       // [GB_MAXK]
-    float *tile = lds + GB_MAXK;           // [(32 + ksize - 1)][64]
-    const int r = ksize / 2, rows = 32 + ksize - 1;
+    float *tile = lds;                     // [(32 + 2r)][64]
+    const int r = ksize / 2, rows = 32 + 2 * r;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int x = blockIdx.x * 64 + tx;
     const int yb = blockIdx.y * 32;
     const size_t b = blockIdx.z;
     const float *s = src + b * (size_t)h * w;
-    for (int i = threadIdx.x; i < ksize; i += 256) kk[i] = kern[i];
     const int xc = x < w ? x : w - 1;
     for (int j = ty; j < rows; j += 4) tile[j * 64 + tx] = s[(size_t)reflect101(yb + j - r, h) * w + xc];
     __syncthreads();
     const int y0 = yb + ty * GC_R;
     if (x >= w || y0 >= h) return;
+    const float *tc = tile + (ty * GC_R + r) * 64 + tx;
     float acc[GC_R];
-#pragma unroll
-    for (int o = 0; o < GC_R; o++) acc[o] = 0.f;
-    const float *t0 = tile + (ty * GC_R) * 64 + tx;
-    // kw[o] = kk[j - o], 0 outside the kernel: one tap read per source row instead of eight, no bounds tests.  A zero tap adds
-    // +-0 to a sum that is never -0 (it starts at +0), so the result is the bit pattern of the tested loop.
-    float kw[GC_R];
-#pragma unroll
-    for (int o = 0; o < GC_R; o++) kw[o] = 0.f;
-    for (int j = 0; j < ksize + GC_R - 1; j++) {
-        const float v = t0[j * 64];
-#pragma unroll
-        for (int o = GC_R - 1; o > 0; o--) kw[o] = kw[o - 1];
-        kw[0] = j < ksize ? kern[j] : 0.f;
-#pragma unroll
-        for (int o = 0; o < GC_R; o++) acc[o] = fmaf(kw[o], v, acc[o]);
-    }
+    gauss_col_symm([&](int i) { return tc[i * 64]; }, kern, r, acc);
 #pragma unroll
     for (int o = 0; o < GC_R; o++)
         if (y0 + o < h) dst[b * (size_t)h * w + (size_t)(y0 + o) * w + x] = acc[o];
@@ -443,14 +439,14 @@ void launch_gauss_rows(const float *src, float *dst, const float *kern, int ksiz
 void launch_gauss_cols(const float *src, float *dst, const float *kern, int ksize, int B, int h, int w, hipStream_t st)
 {
     dim3 grid((w + 63) / 64, (h + 4 * GC_R - 1) / (4 * GC_R), B);
-    const size_t lds = (GB_MAXK + (size_t)(32 + ksize - 1) * 64) * sizeof(float);
+    const size_t lds = (size_t)(32 + 2 * (ksize / 2)) * 64 * sizeof(float);
     if (lds <= 64 * 1024) { hipLaunchKernelGGL(k_gauss_cols_lds, grid, dim3(256), lds, st, src, dst, kern, ksize, h, w); return; }
     hipLaunchKernelGGL(k_gauss_cols, grid, dim3(256), 0, st, src, dst, kern, ksize, h, w);
 }
 
 // Both passes in one kernel for short kernels (ksize <= GF_MAXK): a 64 x 32 output tile with its halo goes through LDS once -- row pass
 // into a second LDS plane (rounded to float exactly as the intermediate plane of the two-kernel path is), column pass out of it -- so the
-// intermediate plane never travels to memory.  Same taps, same order of the fused multiply-adds per output: same bits as the two kernels.
+// intermediate plane never travels to memory.  Same taps, same order of the operations per output: same bits as the two kernels.
 constexpr int GF_TX = 64, GF_TY = 32, GF_MAXK = 15;
 __global__ __launch_bounds__(256) void k_gauss_fused(const float *__restrict__ src, float *__restrict__ dst, const float *__restrict__ kern,
                                                      int ksize, int h, int w)
@@ -476,22 +472,13 @@ __global__ __launch_bounds__(256) void k_gauss_fused(const float *__restrict__ s
         mid_t[i] = acc;
     }
     __syncthreads();
-    // column pass: a thread slides over GC_R output rows of one column (taps outside the kernel are zero: see k_gauss_cols_lds)
+    // column pass: symmetric sum over GC_R output rows of one column (gauss_col_symm)
     const int tx = threadIdx.x & 63, tg = threadIdx.x >> 6;
     const int x = x0 + tx, yb = y0 + tg * GC_R;
     if (x >= w || yb >= h) return;
-    float acc[GC_R], kw[GC_R];
-#pragma unroll
-    for (int o = 0; o < GC_R; o++) { acc[o] = 0.f; kw[o] = 0.f; }
-    const float *t0 = mid_t + (tg * GC_R) * GF_TX + tx;
-    for (int j = 0; j < ksize + GC_R - 1; j++) {
-        const float v = t0[j * GF_TX];
-#pragma unroll
-        for (int o = GC_R - 1; o > 0; o--) kw[o] = kw[o - 1];
-        kw[0] = j < ksize ? kern[j] : 0.f;
-#pragma unroll
-        for (int o = 0; o < GC_R; o++) acc[o] = fmaf(kw[o], v, acc[o]);
-    }
+    const float *tc = mid_t + (tg * GC_R + r) * GF_TX + tx;
+    float acc[GC_R];
+    gauss_col_symm([&](int i) { return tc[i * GF_TX]; }, kern, r, acc);
 #pragma unroll
     for (int o = 0; o < GC_R; o++)
         if (yb + o < h) dst[b * (size_t)h * w + (size_t)(yb + o) * w + x] = acc[o];

@@ -182,14 +182,14 @@ void launch_cc_label(const uint8_t *mask, int32_t *labels, int B, int h, int w, 
     int P = h * w;
     const size_t forest = (size_t)((P + 2 + 7) & ~7) * 2;
     if (P <= 65535 && forest + (size_t)P + 16 <= 160 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_cc_label_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        static DynLdsOnce lds_once;
+        ensure_dyn_lds(lds_once, (const void *)k_cc_label_lds<true>, 160 * 1024);
         hipLaunchKernelGGL(k_cc_label_lds<true>, dim3(B), dim3(1024), forest + (size_t)P + 16, st, mask, labels, h, w);
         return;
     }
     if (P <= 65535 && forest <= 150 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_cc_label_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        static DynLdsOnce lds_once;
+        ensure_dyn_lds(lds_once, (const void *)k_cc_label_lds<false>, 160 * 1024);
         hipLaunchKernelGGL(k_cc_label_lds<false>, dim3(B), dim3(1024), forest, st, mask, labels, h, w);
         return;
     }
@@ -550,15 +550,15 @@ __global__ __launch_bounds__(1024) void k_chamfer_lds(const uint8_t *__restrict_
     }
 }
 
-void launch_chamfer(const uint8_t *src, bool invert, int32_t *rowdist, float *dist, int B, int h, int w, int cap_px, hipStream_t st)
+void launch_chamfer(const uint8_t *src, bool invert, int32_t *rowdist, float *dist, int B, int h, int w, int cap_px, hipStream_t st, bool force_twopass)
 {
     // small caps (the erosion margins): a handful of rows per pixel on 16 waves; for wide bands the per-pixel loop costs more than
     // the one-wave two-pass kernel (measured at cap 46: 345 us against 200 us)
     int cap = (int)((cap_px + 2) / 0.955) + 2;
     if (cap > h) cap = h;
-    if (!getenv("VISTAF_CHAMFER_TWOPASS") && cap <= 16 && (size_t)h * w * 2 <= 150 * 1024 && w <= 512) {
-        static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_chamfer_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    if (!force_twopass && cap <= 16 && (size_t)h * w * 2 <= 150 * 1024 && w <= 512) {
+        static DynLdsOnce lds_once;
+        ensure_dyn_lds(lds_once, (const void *)k_chamfer_lds, 160 * 1024);
         hipLaunchKernelGGL(k_chamfer_lds, dim3(B), dim3(1024), (size_t)h * w * 2, st, src, invert ? 1 : 0, dist, h, w, cap);
         return;
     }
@@ -574,14 +574,14 @@ void launch_chamfer(const uint8_t *src, bool invert, int32_t *rowdist, float *di
 // distance to the zero pixels (-> dist_a) and to the non-zero pixels (-> dist_b) of the same masks.  The two-pass kernel is one wave per
 // frame, so both transforms of a batch run side by side in ONE launch of 2B workgroups (the chip holds four times that many waves).
 void launch_chamfer_pair(const uint8_t *src, int32_t *tmp_a, float *dist_a, int32_t *tmp_b, float *dist_b, int B, int h, int w, int cap_px,
-                         hipStream_t st)
+                         hipStream_t st, bool force_twopass)
 {
     int cap = (int)((cap_px + 2) / 0.955) + 2;
     if (cap > h) cap = h;
-    const bool two_pass = (getenv("VISTAF_CHAMFER_TWOPASS") || cap > 16 || (size_t)h * w * 2 > 150 * 1024) && w <= 512;
+    const bool two_pass = (force_twopass || cap > 16 || (size_t)h * w * 2 > 150 * 1024) && w <= 512;
     if (!two_pass) {
-        launch_chamfer(src, false, tmp_a, dist_a, B, h, w, cap_px, st);
-        launch_chamfer(src, true, tmp_b, dist_b, B, h, w, cap_px, st);
+        launch_chamfer(src, false, tmp_a, dist_a, B, h, w, cap_px, st, false);
+        launch_chamfer(src, true, tmp_b, dist_b, B, h, w, cap_px, st, false);
         return;
     }
     if (w <= 256) hipLaunchKernelGGL(k_chamfer2<4>, dim3(2 * B), dim3(64), 0, st, src, 0, tmp_a, dist_a, tmp_b, dist_b, B, h, w);

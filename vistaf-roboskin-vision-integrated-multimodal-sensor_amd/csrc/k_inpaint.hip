@@ -12,6 +12,7 @@
 // and every store is drained (workgroup fence) before the next dependent read.
 #include <cstdio>
 #include "kernels.hpp"
+#include "telea_common.hpp"
 
 namespace vf {
 
@@ -31,8 +32,14 @@ __device__ inline void drain() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workg
 // pushes are nearly monotone in T, so an insertion shifts only the few trailing entries with a larger T
 // (found and moved by the 64 lanes at once) and lands AFTER every entry with T' <= T (FIFO among ties);
 // pop is the head.  [head, tail) slides up; it is moved back to 0 when the array end is reached.
-__device__ unsigned long long g_telea_dbg[16];   // diagnostic: shader-clock stamps / pop counts of frame 0 (VISTAF_TELEA_DBG)
+// Diagnostic shader-clock stamps / pop counts of frame 0: only in builds with -DVISTAF_DEBUG (the stamps are process-wide globals that
+// concurrent sessions would race on, and s_memtime + a global store per phase is not free on a lone latency-bound wave).
+#ifdef VISTAF_DEBUG
+__device__ unsigned long long g_telea_dbg[16];
 #define TSTAMP(i) do { if (b == 0 && lane == 0) g_telea_dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TSTAMP(i) do { } while (0)
+#endif
 
 __device__ inline uint32_t ldq(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -321,7 +328,7 @@ __global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const
                     if (kd) gty = ku ? __fmul_rn(__fsub_rn(td, tu), 0.5f) : __fsub_rn(td, tc);
                     else gty = ku ? __fsub_rn(tc, tu) : 0.f;
                 }
-                float sIa = 0, sJx = 0, sJy = 0, sS = 0;
+                float sIa = 0, sJx = 0, sJy = 0, sS = 1.0e-20f;     // running sums in OpenCV's order (wn_seq_sum_n): chunk after chunk, lane after lane
                 for (int n0 = 0; n0 < nn; n0 += 64) {
                     int nidx = n0 + lane;
                     float cIa = 0.f, cJx = 0.f, cJy = 0.f, cS = 0.f;
@@ -356,14 +363,13 @@ __global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const
                             }
                         }
                     }
-                    sIa += dpp_sum_f32(cIa);
-                    sJx -= dpp_sum_f32(cJx);
-                    sJy -= dpp_sum_f32(cJy);
-                    sS += dpp_sum_f32(cS);
+                    const int nl = nn - n0 < 64 ? nn - n0 : 64;
+                    sIa = wn_seq_sum_n(cIa, sIa, nl, lane);
+                    sJx = wn_seq_sum_n(-cJx, sJx, nl, lane);
+                    sJy = wn_seq_sum_n(-cJy, sJy, nl, lane);
+                    sS = wn_seq_sum_n(cS, sS, nl, lane);
                 }
-                float Ia = sIa, Jx = sJx, Jy = sJy, s = sS + 1.0e-20f;
-                float val = (float)((double)__fdiv_rn(Ia, s) +
-                                    (double)__fadd_rn(Jx, Jy) / (sqrt((double)__fadd_rn(__fmul_rn(Jx, Jx), __fmul_rn(Jy, Jy))) + (double)1.0e-20f));
+                float val = telea_estimate(sIa, sJx, sJy, sS);
                 if (lane == 0) { img[(size_t)(i - 1) * w + (j - 1)] = val; f[pi] = T_BAND; }
                 tq_push<LF>(q, dist, pi, lane);
                 if (LF) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -371,10 +377,13 @@ __global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const
         }
     }
     TSTAMP(6);
+#ifdef VISTAF_DEBUG
     if (b == 0 && lane == 0) { g_telea_dbg[8] = npop1; g_telea_dbg[9] = npop2; g_telea_dbg[10] = (unsigned long long)nbad; }
+#endif
     if (q.overflow && lane == 0) status[b] = 2;
 }
 
+#ifdef VISTAF_DEBUG
 void telea_debug_dump()
 {
     unsigned long long h[16];
@@ -382,6 +391,7 @@ void telea_debug_dump()
     printf("[telea dbg] cycles: init %llu | pass1 seeds %llu | pass1 queue %llu | negate %llu | pass2 seeds %llu | pass2 queue %llu | pops %llu / %llu | bad %llu\n",
            h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[8], h[9], h[10]);
 }
+#endif
 
 size_t inpaint_scratch_bytes_per_frame(int h, int w)
 {
@@ -408,8 +418,8 @@ void launch_inpaint_telea(float *img, const uint8_t *bad, int range, void *scrat
     hipLaunchKernelGGL(k_telea_prep, dim3((unsigned)((en + 255) / 256), B), dim3(256), 0, st, bad, gflags, gT, nbad, only, range, h, w);
     size_t lds_full = telea_lds_bytes(h, w);
     if (lds_full <= 160 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) { hipFuncSetAttribute((const void *)k_telea<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        static DynLdsOnce lds_once;
+        ensure_dyn_lds(lds_once, (const void *)k_telea<true>, 160 * 1024);
         hipLaunchKernelGGL(k_telea<true>, dim3(B), dim3(64), lds_full, st, img, bad, range, gflags, gT, gqueue, nbad, status, h, w);
     } else {
         hipLaunchKernelGGL(k_telea<false>, dim3(B), dim3(64), 0, st, img, bad, range, gflags, gT, gqueue, nbad, status, h, w);

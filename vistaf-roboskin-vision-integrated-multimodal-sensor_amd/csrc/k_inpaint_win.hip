@@ -32,8 +32,13 @@ constexpr int WN_RING_U = 6;         // inpaint ranges up to this have their rin
 constexpr int WN_QCAP = 4096;       // live queue entries (8 B each)
 constexpr int WN_CELLS = 14464;     // window cells (9 B each: T f32, image f32, flags u8)
 
-__device__ unsigned long long g_win_dbg[1024][16];   // diagnostic shader-clock stamps per frame (VISTAF_TELEA_DBG)
+// diagnostic shader-clock stamps per frame: only in builds with -DVISTAF_DEBUG (see k_inpaint.hip)
+#ifdef VISTAF_DEBUG
+__device__ unsigned long long g_win_dbg[1024][16];
 #define WSTAMP(i) do { if (!CL && lane == 0 && b < 1024) g_win_dbg[b][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WSTAMP(i) do { } while (0)
+#endif
 
 
 // box planes [4][B]: xmin, ymin (start 0x7f7f7f7f), xmax, ymax (start 0) of the hole pixels of each frame
@@ -281,10 +286,18 @@ __device__ inline bool wn_march(float *__restrict__ img, const uint8_t *__restri
             }
         }
     };
-    if (mc.nn <= 64) march(std::true_type{});
-    else march(std::false_type{});
+    // discs of the inpaint ranges 1..4 (5, 13, 29, 49 positions): straight-line estimator with that many lanes; anything else: chunk loop
+    switch (mc.ndisc) {
+    case 5: march(std::integral_constant<int, 5>{}); break;
+    case 13: march(std::integral_constant<int, 13>{}); break;
+    case 29: march(std::integral_constant<int, 29>{}); break;
+    case 49: march(std::integral_constant<int, 49>{}); break;
+    default: march(std::integral_constant<int, 0>{}); break;
+    }
     WSTAMP(7);
+#ifdef VISTAF_DEBUG
     if (!CL && lane == 0 && b < 1024) { g_win_dbg[b][8] = (np1 << 32) | np2; g_win_dbg[b][9] = (nfill << 32) | (unsigned)cells; g_win_dbg[b][10] = ns1; }
+#endif
     if (q.ovf) return false;
     // ---- write back the hole pixels
     for (int r = 0; r < wh; r++) {
@@ -361,6 +374,7 @@ void launch_telea_clusters2(float *img, const uint8_t *bad, const int32_t *label
     hipLaunchKernelGGL(k_telea_clusters2, dim3(CL2_SLOTS, B), dim3(64), lds, st, img, bad, labels, list, count, xmin, ymin, xmax, ymax, big, range, h, w);
 }
 
+#ifdef VISTAF_DEBUG
 void telea_window_debug_dump(int B)
 {
     static unsigned long long hbuf[1024][16];
@@ -378,6 +392,7 @@ void telea_window_debug_dump(int B)
                x[8] >> 32, x[10], x[8] & 0xffffffffull, x[9] >> 32, x[9] & 0xffffffffull, mean);
     }
 }
+#endif
 
 size_t inpaint_win_scratch_bytes(int B) { return (size_t)B * 5 * sizeof(int32_t) + 256; }
 
@@ -391,8 +406,8 @@ int32_t *launch_inpaint_window(float *img, const uint8_t *bad, int range, void *
     if (P % 16 == 0) hipLaunchKernelGGL(k_bad_bbox<true>, dim3((P / 16 + 255) / 256, B), dim3(256), 0, st, bad, box, B, h, w);
     else hipLaunchKernelGGL(k_bad_bbox<false>, dim3((P + 255) / 256, B), dim3(256), 0, st, bad, box, B, h, w);
     const size_t lds = (size_t)WN_CELLS * 9 + (size_t)WN_QCAP * 8 + 256;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_telea_window, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    static DynLdsOnce lds_once;
+        ensure_dyn_lds(lds_once, (const void *)k_telea_window, 160 * 1024);
     if (ev_march) (void)hipEventRecord(ev_march, st);     // stage timing: the march starts here (the bbox pass belongs to the mask stage)
     hipLaunchKernelGGL(k_telea_window, dim3(B), dim3(64), lds, st, img, bad, box, fb, range, B, h, w);
     return fb;

@@ -209,7 +209,7 @@ size_t unwrap_scratch_bytes_per_frame(int h, int w)
 bool unwrap_ranked_supported(int h, int w);
 bool launch_unwrap_ranked(const float *quality, const uint8_t *mask, uint32_t *g0, uint32_t *g1, uint32_t *g2, uint32_t *g3,
                           int32_t *ppar, size_t gstride, uint16_t *rank16, int32_t *seed, int32_t *status, int B, int h, int w,
-                          hipStream_t st, hipEvent_t ev_flood);
+                          hipStream_t st, hipEvent_t ev_flood, int flood_tier);
 void launch_unwrap_replay(const float *wrapped, const uint32_t *order, size_t ostride, const int32_t *ppar, size_t gstride, int32_t *tree,
                           float *unwrapped, int B, int h, int w, hipStream_t st);
 
@@ -221,7 +221,7 @@ static int unwrap_lds_cap(int P)
 }
 
 void launch_unwrap(const float *wrapped, const float *quality, const uint8_t *mask, float *unwrapped, int32_t *parent,
-                   void *scratch, int32_t *status, int B, int h, int w, hipStream_t st, hipEvent_t ev_mid, hipEvent_t ev_flood)
+                   void *scratch, int32_t *status, int B, int h, int w, hipStream_t st, hipEvent_t ev_mid, hipEvent_t ev_flood, int flood_tier)
 {
     int P = h * w;
     size_t n = (size_t)B * P;
@@ -238,7 +238,7 @@ void launch_unwrap(const float *wrapped, const float *quality, const uint8_t *ma
         after = (uint8_t *)(((uintptr_t)after + 255) & ~(uintptr_t)255);
         uint16_t *rank16 = (uint16_t *)after;
         int32_t *seed = (int32_t *)(after + (((gn + 8 * (size_t)B) * 2 + 255) & ~(size_t)255));
-        bool logged = launch_unwrap_ranked(quality, mask, g0, g1, g2, g3, (int32_t *)g4, EN, rank16, seed, status, B, h, w, st, ev_flood);
+        bool logged = launch_unwrap_ranked(quality, mask, g0, g1, g2, g3, (int32_t *)g4, EN, rank16, seed, status, B, h, w, st, ev_flood, flood_tier);
         ppar = (const int32_t *)g4;
         if (logged) {
             if (ev_mid) hipEventRecord(ev_mid, st);
@@ -247,8 +247,8 @@ void launch_unwrap(const float *wrapped, const float *quality, const uint8_t *ma
         }
     } else if (cap > 0) {
         if (ev_flood) hipEventRecord(ev_flood, st);
-        static bool attr_set = false;
-        if (!attr_set) { hipFuncSetAttribute((const void *)k_unwrap_flood<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        static DynLdsOnce lds_once;
+        ensure_dyn_lds(lds_once, (const void *)k_unwrap_flood<true>, 160 * 1024);
         size_t lds = (size_t)cap * 8 + ((P + 15) & ~15);
         hipLaunchKernelGGL(k_unwrap_flood<true>, dim3(B), dim3(64), lds, st, quality, mask, parent, gst, g0, g1, cap, status, h, w);
     } else {

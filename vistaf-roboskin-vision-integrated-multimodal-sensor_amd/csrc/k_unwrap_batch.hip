@@ -328,8 +328,8 @@ void launch_unwrap_flood_batch(const uint16_t *rank16, const int32_t *seed, cons
 {
     long EN = (long)(h + 2) * (w + 2);
     size_t lds = (size_t)(((EN + 7) & ~7L)) * 2 + (BT_NW + 16) * 8 + 256 + 512;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_unwrap_flood_batch, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    static DynLdsOnce lds_once;
+        ensure_dyn_lds(lds_once, (const void *)k_unwrap_flood_batch, 160 * 1024);
     const uint32_t magic = (uint32_t)(0x100000000ull / (unsigned)(w + 2)) + 1u;     // idx / (w + 2) == umulhi(idx, magic) for idx < 65536
     hipLaunchKernelGGL(k_unwrap_flood_batch, dim3(B), dim3(64), lds, st, rank16, seed, inv, inv_stride, ppar, gstride, order, ostride, h, w, magic);
 }
@@ -340,8 +340,8 @@ void launch_unwrap_replay(const float *wrapped, const uint32_t *order, size_t os
 {
     long EN = (long)(h + 2) * (w + 2);
     size_t lds = (size_t)(((EN + 7) & ~7L)) * 2;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_unwrap_replay, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    static DynLdsOnce lds_once;
+        ensure_dyn_lds(lds_once, (const void *)k_unwrap_replay, 160 * 1024);
     const uint32_t magic = (uint32_t)(0x100000000ull / (unsigned)(w + 2)) + 1u;
     hipLaunchKernelGGL(k_unwrap_replay, dim3(B), dim3(64 * RP_NW), lds, st, wrapped, order, ostride, ppar, gstride, tree, unwrapped, h, w, magic);
 }

@@ -203,8 +203,8 @@ void launch_unwrap_flood_hot(const uint16_t *rank16, const int32_t *seed, const 
 {
     long EN = (long)(h + 2) * (w + 2);
     size_t lds = (size_t)(((EN + 7) & ~7L)) * 2 + (HOT_NW + 16) * 8 + 256;
-    static bool attr_set = false;
-    if (!attr_set) { hipFuncSetAttribute((const void *)k_unwrap_flood_hot, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    static DynLdsOnce lds_once;
+        ensure_dyn_lds(lds_once, (const void *)k_unwrap_flood_hot, 160 * 1024);
     hipLaunchKernelGGL(k_unwrap_flood_hot, dim3(B), dim3(64), lds, st, rank16, seed, inv, inv_stride, ppar, gstride, status, h, w);
 }
 

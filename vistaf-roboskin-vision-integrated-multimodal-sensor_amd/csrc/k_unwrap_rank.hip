@@ -323,21 +323,20 @@ bool unwrap_ranked_supported(int h, int w)
 // returns true when the growth kernel also left its pop records in g2 (stride 2 * gstride per frame) for launch_unwrap_replay
 bool launch_unwrap_ranked(const float *quality, const uint8_t *mask, uint32_t *g0, uint32_t *g1, uint32_t *g2, uint32_t *g3,
                           int32_t *ppar, size_t gstride, uint16_t *rank16, int32_t *seed, int32_t *status, int B, int h, int w,
-                          hipStream_t st, hipEvent_t ev_flood)
+                          hipStream_t st, hipEvent_t ev_flood, int flood_tier)
 {
     int EN = (h + 2) * (w + 2);
     int cap = ranked_cap(EN);
     // g0|g1 and g2|g3 are contiguous (k_unwrap.hip): two planes of 8-byte sort records; the sorted pixel indices go to g2
     (void)g1; (void)g3;
-    static bool rk_attr = false;
-    if (!rk_attr) { (void)hipFuncSetAttribute((const void *)k_unwrap_rank, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * RK_NB * (int)sizeof(uint32_t)); rk_attr = true; }   // + 64 B static
+    static DynLdsOnce rank_once;
+    ensure_dyn_lds(rank_once, (const void *)k_unwrap_rank, 16 * RK_NB * (int)sizeof(uint32_t));   // + 64 B static
     hipLaunchKernelGGL(k_unwrap_rank, dim3(B), dim3(RK_T), (size_t)16 * RK_NB * sizeof(uint32_t), st, quality, mask, (unsigned long long *)g0,
                        (unsigned long long *)g2, gstride, rank16, seed, h, w);
     if (ev_flood) hipEventRecord(ev_flood, st);
-    // growth loop: "batch" (default: 8 pops per step, k_unwrap_batch.hip), "hot" (one pop per step, sorted register list + rank
-    // bitmap) or "scan" (frontier array scan)
-    const char *e = getenv("VISTAF_FLOOD");                     // read on every call: the parity tests switch between the kernels
-    const int use_hot = (e && !strcmp(e, "scan")) ? 0 : (e && !strcmp(e, "hot")) ? 1 : 2;
+    // growth loop (Tiers::flood): 2 = "batch" (default: 8 pops per step, k_unwrap_batch.hip), 1 = "hot" (one pop per step, sorted
+    // register list + rank bitmap), 0 = "scan" (frontier array scan)
+    const int use_hot = flood_tier;
     if (use_hot == 2 && unwrap_batch_supported(h, w)) {
         // sorted pixel indices: g0 (stride 2 * gstride); the sort records in g2|g3 are dead once the ranks are out: the growth
         // kernel logs its pops there
@@ -348,8 +347,8 @@ bool launch_unwrap_ranked(const float *quality, const uint8_t *mask, uint32_t *g
         launch_unwrap_flood_hot(rank16, seed, g0, 2 * gstride, ppar, gstride, status, B, h, w, st);
         return false;
     }
-    static bool attr_set = false;
-    if (!attr_set) { hipFuncSetAttribute((const void *)k_unwrap_flood_ranked, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    static DynLdsOnce lds_once;
+    ensure_dyn_lds(lds_once, (const void *)k_unwrap_flood_ranked, 160 * 1024);
     size_t lds = (size_t)((EN + 7) & ~7) * 2 + (size_t)cap * 4;
     hipLaunchKernelGGL(k_unwrap_flood_ranked, dim3(B), dim3(64), lds, st, rank16, seed, ppar, gstride, cap, status, h, w);
     return false;

@@ -7,6 +7,14 @@
 
 namespace vf {
 
+// Which of the parity-equivalent kernels a stage runs.  Defaults are the production kernels; the alternatives are fallbacks for
+// sizes the defaults do not cover and stay selectable so the parity tests can pin them against the defaults (csrc/test_hooks.h).
+struct Tiers {
+    int inpaint = 2;            // 2: frame-window march (k_telea_window) + whole-frame fallback; 1: whole-frame kernel only; 0: cluster front end first
+    int flood = 2;              // 2: batched pops (k_unwrap_flood_batch); 1: one pop per step (k_unwrap_flood_hot); 0: frontier scan
+    int chamfer_twopass = 0;    // 1: force the one-wave two-pass chamfer even where the LDS closed form applies
+};
+
 struct RowSpanSE {      // structuring element as per-row x spans (cv::getStructuringElement ELLIPSE)
     int k;              // k x k, anchor at centre (k <= 33)
     int8_t lo[33];      // relative x offset of first set element in row i (lo > hi: empty row)
@@ -36,25 +44,42 @@ void launch_count_u8(const uint8_t *m, int *counts, int B, int P, hipStream_t st
 void launch_select(const float *vals, const uint8_t *mask, size_t mask_stride, const float *le_thr, bool use_abs,
                    const float *reqs_dev, int nreq, float *out, int *counts, int B, int P, hipStream_t st);
 
-// ---- k_dft.hip --------------------------------------------------------------------------------
-void launch_dft_forward(const float *iw, const float *mu, const float2 *Ex, const float2 *Ey, const float *win,
-                        float2 *tmpT, float2 *patch, int B, int h, int w, int ph, int pw, hipStream_t st);
-void launch_dft_inverse(const float2 *patch, const float2 *Gx, const float2 *Gy, float2 *tmpQ, float2 *field, float *amp,
-                        int B, int h, int w, int ph, int pw, hipStream_t st);
-void launch_dft_full_mag(const float *iw, const float *mu, const float2 *Ex_full, const float2 *Ey_full, float2 *tmp,
-                         float *mag, int h, int w, int Hf, int Wf, int dc_excl, hipStream_t st);
-void launch_top_peaks(const float *mag, int Hf, int Wf, int dc, int npeaks, float *out_xyv, hipStream_t st);
-void launch_phase_diff(const float2 *cdef, const float2 *cref, const float *amp_def, const float *amp_ref, float *prod,
-                       float *wrapped, int B, int P, hipStream_t st);
+// ---- k_dft.hip / k_dft_tables.hip ----------------------------------------------------------------
+// carrier of one reference frame (shape_ftp.py:878-913, :930-961)
+struct CarrierGeom {
+    double peak_x, peak_y;      // refined peak (fftshift layout)
+    double kx, ky;              // carrier in bins
+    double dpx, dpy;            // sub-bin remainder handled by the ramp (0 when both <= 1e-6)
+    double period;              // Wf / |kx| (0: invalid)
+    int x0, y0, ph, pw;         // patch origin and size in the shifted spectrum
+    int px_i, py_i;
+    int ok, pad_;
+};
+// table strides are in elements per frame (0: one table for the whole batch)
+void launch_dft_forward(const float *iw, const float *mu, const double2 *Ex, const double2 *Ey, size_t tab_stride_x, size_t tab_stride_y,
+                        const float *win, double2 *tmpT, double2 *patch, int patch_stride, int B, int h, int w, int ph, int pw, hipStream_t st);
+// field (may be null): float64 field out; cref/amp_ref (may be null): reference field -> wrapped phase difference and amp product
+void launch_dft_inverse(const double2 *patch, int patch_stride, const double2 *Gx, const double2 *Gy, size_t tab_stride_x, size_t tab_stride_y,
+                        double2 *tmpQ, double2 *field, float *amp, const double2 *cref, const float *amp_ref, size_t ref_stride, float *prod,
+                        float *wrapped, int B, int h, int w, int ph, int pw, hipStream_t st);
+void launch_dft_full_mag(const float *iw, const float *mu, const double2 *Ex_full, const double2 *Ey_full, double2 *tmp,
+                         double *mag, int B, int h, int w, int Hf, int Wf, hipStream_t st);
+void launch_top_peaks(const double *mag, int B, int Hf, int Wf, int dc, int npeaks, double *out_xyv /* [B][192] */, hipStream_t st);
+void launch_carrier_choose(const double *peaks, int npk, const double *mag, int Hf, int Wf, int bw, double max_dy_frac, CarrierGeom *geom, int B,
+                           hipStream_t st);
+void launch_build_tables(const CarrierGeom *geom, int geom_stride, double2 *Ex, double2 *Ey, double2 *Gx, double2 *Gy, size_t stride_x,
+                         size_t stride_y, int B, int h, int w, int pad, int Hf, int Wf, int pmax, hipStream_t st);
+void launch_build_full_tables(double2 *Exf, double2 *Eyf, int h, int w, int pad, int Hf, int Wf, hipStream_t st);
 
 // ---- k_cc_dist.hip ----------------------------------------------------------------------------
 void launch_threshold_mask(const float *q, const uint8_t *roi, const float *thr, uint8_t *out, int B, int P, hipStream_t st);
 void launch_cc_label(const uint8_t *mask, int32_t *labels, int B, int h, int w, hipStream_t st);
 void launch_cc_largest(const int32_t *labels, int32_t *area_scratch, unsigned long long *best, const uint8_t *and_static,
                        uint8_t *out, int B, int P, hipStream_t st);
-void launch_chamfer(const uint8_t *src, bool invert, int32_t *rowdist, float *dist, int B, int h, int w, int cap_px, hipStream_t st);
+void launch_chamfer(const uint8_t *src, bool invert, int32_t *rowdist, float *dist, int B, int h, int w, int cap_px, hipStream_t st,
+                    bool force_twopass = false);
 void launch_chamfer_pair(const uint8_t *src, int32_t *tmp_a, float *dist_a, int32_t *tmp_b, float *dist_b, int B, int h, int w, int cap_px,
-                         hipStream_t st);
+                         hipStream_t st, bool force_twopass = false);
 void launch_erode_by_dist(const float *dist, const uint8_t *src, float margin, uint8_t *out, int B, int P, hipStream_t st);
 
 // ---- k_inpaint.hip ----------------------------------------------------------------------------
@@ -78,7 +103,7 @@ void launch_inpaint_clusters(float *img, const uint8_t *bad, int range, void *sc
 size_t unwrap_scratch_bytes_per_frame(int h, int w);
 void launch_unwrap(const float *wrapped, const float *quality, const uint8_t *mask, float *unwrapped, int32_t *parent,
                    void *scratch, int32_t *status, int B, int h, int w, hipStream_t st, hipEvent_t ev_mid,
-                   hipEvent_t ev_flood = nullptr);
+                   hipEvent_t ev_flood = nullptr, int flood_tier = 2);
 
 // ---- k_fit.hip --------------------------------------------------------------------------------
 void launch_robust_polyfit(const float *z, const uint8_t *mask, int order, int iters, float c, int min_count, float *coef_out,

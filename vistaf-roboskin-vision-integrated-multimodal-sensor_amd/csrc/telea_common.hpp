@@ -20,6 +20,57 @@ __device__ inline float wn_dpp_sum(float x)
 }
 __device__ inline float wn_lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
+// Sum over lanes [0, N) in LANE ORDER from `init`: ((init + x0) + x1) + ... + x(N-1), every addition rounded to float.  That is the order
+// in which cv::inpaint's k / l loops accumulate Ia, Jx, Jy and s (inpaint.cpp icvTeleaInpaintFMM; restated in oracle/cvlite.c), so the
+// filled pixels carry the same roundings bit for bit -- they feed the illumination blur, the demodulation and, through the amplitude, the
+// quality >= p25 threshold of the reliable mask.  After step t lanes 0..t hold their final prefix (lane l takes lane l-1's value through
+// wave_shr:1 and adds its own term; a lane that is already final recomputes the same value), so N-1 dependent DPP adds give the total.
+// A tree reduction is ~6 steps instead of N-1 but rounds differently (up to 1e-6 relative on a filled pixel).
+template <int N>
+__device__ __attribute__((always_inline)) inline float wn_seq_sum(float x, float init, int lane)
+{
+    const float xi = lane == 0 ? __fadd_rn(init, x) : x;
+    float S = xi;
+#pragma unroll
+    for (int t = 1; t < N; t++)
+        S = __fadd_rn(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(S), 0x138, 0xf, 0xf, true)), xi);     // lane 0: 0 + xi
+    return wn_lane_f(S, N - 1);
+}
+// the four estimator sums side by side: four independent chains, so a step issues back to back instead of waiting out the DPP hazard
+template <int N>
+__device__ __attribute__((always_inline)) inline void wn_seq_sum4(float &a, float &b, float &c, float &d, float init_d, int lane)
+{
+    const float xd = lane == 0 ? __fadd_rn(init_d, d) : d;      // a, b, c start at +0: 0 + x = x
+    float Sa = a, Sb = b, Sc = c, Sd = xd;
+#pragma unroll
+    for (int t = 1; t < N; t++) {
+        const float pa = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(Sa), 0x138, 0xf, 0xf, true));
+        const float pb = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(Sb), 0x138, 0xf, 0xf, true));
+        const float pc = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(Sc), 0x138, 0xf, 0xf, true));
+        const float pd = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(Sd), 0x138, 0xf, 0xf, true));
+        Sa = __fadd_rn(pa, a); Sb = __fadd_rn(pb, b); Sc = __fadd_rn(pc, c); Sd = __fadd_rn(pd, xd);
+    }
+    a = wn_lane_f(Sa, N - 1); b = wn_lane_f(Sb, N - 1); c = wn_lane_f(Sc, N - 1); d = wn_lane_f(Sd, N - 1);
+}
+// runtime length (n uniform, 1 <= n <= 64): the general estimator path and the whole-frame kernel
+__device__ inline float wn_seq_sum_n(float x, float init, int n, int lane)
+{
+    const float xi = lane == 0 ? __fadd_rn(init, x) : x;
+    float S = xi;
+    for (int t = 1; t < n; t++)
+        S = __fadd_rn(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(S), 0x138, 0xf, 0xf, true)), xi);
+    return wn_lane_f(S, n - 1);
+}
+// Ia / s + (Jx + Jy) / (sqrt(Jx^2 + Jy^2) + 1e-20): the float quotient and sums promoted to double for the second term and the final
+// addition, as the oracle restates OpenCV's expression
+__device__ inline float telea_estimate(float Ia, float Jx, float Jy, float s)
+{
+    return (float)((double)__fdiv_rn(Ia, s) +
+                   (double)__fadd_rn(Jx, Jy) / (sqrt((double)__fadd_rn(__fmul_rn(Jx, Jx), __fmul_rn(Jy, Jy))) + (double)1.0e-20f));
+}
+// 1 / (1 + |T - Tc|) formed in double and rounded to float (inpaint.cpp: lev = (float)(1./(1+fabs(...))))
+__device__ inline float telea_lev(float tk, float tc) { return (float)(1.0 / (1.0 + (double)fabsf(__fsub_rn(tk, tc)))); }
+
 // Stable priority queue (T, push order), the semantics of OpenCV's CvPriorityQueueFloat.  Two sorted runs:
 //   * COLD: a sorted array of (T bits << 32 | cell) words in LDS, popped at its head;
 //   * HOT: the newest <= 64 pushes, sorted, one per lane in registers.  A push is a branch-free insertion
@@ -200,6 +251,7 @@ __device__ inline TeleaOutsideConsts telea_outside_consts(int lane, int ww)
 // this lane's neighbour offsets of the first two 64-neighbour chunks of the (2*range+1)^2 estimator window
 struct TeleaMarchConsts {
     int off[2], d4, range, nn, side, r2;
+    int ndisc;                  // window positions inside the disc dk^2 + dl^2 <= range^2
     float rx[2], ry[2], dstw[2];
     bool on[2];
 };
@@ -207,11 +259,23 @@ __device__ inline TeleaMarchConsts telea_march_consts(int lane, int ww, int rang
 {
     TeleaMarchConsts c;
     c.range = range; c.r2 = range * range; c.side = 2 * range + 1; c.nn = c.side * c.side;
+    // When the disc has at most 64 positions (range <= 4) lane i takes the i-th of them in row-major order: positions outside the disc never
+    // contribute, and the sequential sums then need ndisc - 1 steps instead of side^2 - 1.  Larger ranges: all side^2 positions, row-major.
+    int nd = 0, mine = -1;
+    for (int i = 0; i < c.nn; i++) {
+        const int dk = i / c.side - range, dl = i % c.side - range;
+        if (dl * dl + dk * dk <= c.r2) { if (nd == lane) mine = i; nd++; }
+    }
+    c.ndisc = nd;
+    const bool compact = nd <= 64;
+    if (compact) c.nn = nd;                 // one chunk
 #pragma unroll
     for (int c2 = 0; c2 < 2; c2++) {
         int nidx = c2 * 64 + lane;
+        bool valid = nidx < c.nn;
+        if (compact) { valid = c2 == 0 && mine >= 0; nidx = valid ? mine : 0; }
         int dk = nidx / c.side - range, dl = nidx % c.side - range;
-        c.on[c2] = nidx < c.nn && (dl * dl + dk * dk <= c.r2);
+        c.on[c2] = valid && (dl * dl + dk * dk <= c.r2);
         c.off[c2] = c.on[c2] ? dk * ww + dl : 0;              // lanes that are off may read, unused, the centre pixel
         float ry = (float)(-dk), rx = (float)(-dl);
         c.rx[c2] = rx; c.ry[c2] = ry;
@@ -345,8 +409,9 @@ __device__ __attribute__((always_inline)) inline int telea_pop_outside4(const Te
 
 // Telea march (icvTeleaInpaintFMM): pop p, fill every 4-neighbour that is still INSIDE and push it.  Returns the number of
 // pixels filled.
-// SMALL: the estimator window fits one 64-lane chunk ((2 * range + 1)^2 <= 64), the case of every shipped configuration.
-template <bool SMALL, class Push>
+// NS > 0: the disc of the estimator window has NS <= 64 positions, one per lane (telea_march_consts), the case of every shipped
+// configuration (range 3: 29); NS == 0: general chunk loop.
+template <int NS, class Push>
 __device__ __attribute__((always_inline)) inline int telea_pop_march(const TeleaWin &win, const TeleaMarchConsts &mc, int p, bool from_queue, int lane,
                                                                      Push push)
 {
@@ -365,8 +430,8 @@ __device__ __attribute__((always_inline)) inline int telea_pop_march(const Telea
         todo &= todo - 1;
         const int pi = p + (qn == 0 ? -ww : qn == 1 ? -1 : qn == 2 ? ww : 1);
         nfill++;
-        if constexpr (SMALL) {
-            // One estimator chunk (side^2 <= 64), written as ONE basic block: on a lone wave a taken branch costs tens of cycles and a
+        if constexpr (NS > 0) {
+            // One estimator chunk (disc <= 64 positions), written as ONE basic block: on a lone wave a taken branch costs tens of cycles and a
             // dependent instruction ~9, so every LDS read is issued up front (the T word read at pi itself is the stale one, but
             // pi is INSIDE and never enters the sums), every condition is a per-lane select, and the quadrant solve (an f64 chain)
             // overlaps the image-gradient terms of the estimator.  Lanes that are off read, unused, around pi itself.
@@ -399,7 +464,7 @@ __device__ __attribute__((always_inline)) inline int telea_pop_march(const Telea
             const float gty_d = ku ? gy2 : gyd, gty_n = ku ? gyu : 0.f, gty = kd ? gty_d : gty_n;
             const float rx = h_rx[0], ry = h_ry[0];
             const bool use = (int)h_on[0] & (int)((f0 & W_BORDER) == 0) & (int)((f0 & W_ST) != W_INSIDE);
-            const float lev = __fdiv_rn(1.0f, __fadd_rn(1.0f, fabsf(__fsub_rn(tk, tc))));
+            const float lev = telea_lev(tk, tc);
             float dir = __fadd_rn(__fmul_rn(rx, gtx), __fmul_rn(ry, gty));
             dir = fabsf(dir) <= 0.01f ? 0.000001f : dir;          // float(0.01) < 0.01: same set of floats as the double compare
             const float wgt = fabsf(__fmul_rn(__fmul_rn(h_dstw[0], lev), dir));
@@ -408,14 +473,15 @@ __device__ __attribute__((always_inline)) inline int telea_pop_march(const Telea
             const float iy2 = __fmul_rn(__fsub_rn(vE, vF), 2.0f), iyd = __fsub_rn(vE, vC), iyu = __fsub_rn(vG, vF);
             const float gix_r = nl ? ix2 : ixr, gix_n = nl ? ixl : 0.f, gix = nr ? gix_r : gix_n;
             const float giy_d = nu ? iy2 : iyd, giy_n = nu ? iyu : 0.f, giy = nd ? giy_d : giy_n;
-            const float z = 0.f;                                  // the sums start at +0, as in the chunk loop of the general variant
-            const float aIa = use ? __fadd_rn(z, __fmul_rn(wgt, vC)) : z;
-            const float aJx = use ? __fsub_rn(z, __fmul_rn(wgt, __fmul_rn(gix, rx))) : z;
-            const float aJy = use ? __fsub_rn(z, __fmul_rn(wgt, __fmul_rn(giy, ry))) : z;
-            const float aS = use ? __fadd_rn(z, wgt) : z;
-            const float Ia = wn_dpp_sum(aIa), Jx = wn_dpp_sum(aJx), Jy = wn_dpp_sum(aJy), s = __fadd_rn(wn_dpp_sum(aS), 1.0e-20f);
-            const float nrm = __fadd_rn(__fsqrt_rn(__fadd_rn(__fmul_rn(Jx, Jx), __fmul_rn(Jy, Jy))), 1.0e-20f);
-            const float val = __fadd_rn(__fdiv_rn(Ia, s), __fdiv_rn(__fadd_rn(Jx, Jy), nrm));
+            // terms of Ia += w * I, Jx -= w * (gix * rx), Jy -= w * (giy * ry), s += w (s starts at 1e-20f); a skipped position adds 0
+            const float z = 0.f;
+            const float aIa = use ? __fmul_rn(wgt, vC) : z;
+            const float aJx = use ? -__fmul_rn(wgt, __fmul_rn(gix, rx)) : z;
+            const float aJy = use ? -__fmul_rn(wgt, __fmul_rn(giy, ry)) : z;
+            const float aS = use ? wgt : z;
+            float Ia = aIa, Jx = aJx, Jy = aJy, s = aS;
+            wn_seq_sum4<NS>(Ia, Jx, Jy, s, 1.0e-20f, lane);
+            const float val = telea_estimate(Ia, Jx, Jy, s);
             if (lane == 0) { im[pi] = val; f[pi] = (uint8_t)(W_HOLE | W_BAND); }
             push(tc, pi);
             continue;
@@ -443,8 +509,9 @@ __device__ __attribute__((always_inline)) inline int telea_pop_march(const Telea
         else gtx = kl ? __fsub_rn(tc, tl) : 0.f;
         if (kd) gty = ku ? __fmul_rn(__fsub_rn(td, tu), 0.5f) : __fsub_rn(td, tc);
         else gty = ku ? __fsub_rn(tc, tu) : 0.f;
-        float aIa = 0.f, aJx = 0.f, aJy = 0.f, aS = 0.f;
+        float Ia = 0.f, Jx = 0.f, Jy = 0.f, s = 1.0e-20f;       // running sums in OpenCV's order: chunk after chunk, lane after lane
         for (int n0 = 0; n0 < nn; n0 += 64) {
+            float aIa = 0.f, aJx = 0.f, aJy = 0.f, aS = 0.f;
             int off;
             float dstw, rx, ry;
             bool on;
@@ -473,9 +540,7 @@ __device__ __attribute__((always_inline)) inline int telea_pop_march(const Telea
                         vC = im[rowm + sl]; vA = im[rowm + 1 - sL]; vB = im[rowm + sl - 1]; vD = im[rowm - sL];
                         vE = im[pk + (1 - sK) * ww + sl]; vF = im[rowm - ww + sl]; vG = im[pk - sK * ww + sl];
                     }
-                    // 1 / (1 + |T - Tc|): OpenCV forms it in double and rounds to float; the float quotient differs
-                    // from that by at most one ulp of a weight, far inside the estimator's own rounding noise
-                    float lev = __fdiv_rn(1.0f, __fadd_rn(1.0f, fabsf(__fsub_rn(tk, tc))));
+                    float lev = telea_lev(tk, tc);
                     float dir = __fadd_rn(__fmul_rn(rx, gtx), __fmul_rn(ry, gty));
                     if (fabsf(dir) <= 0.01f) dir = 0.000001f;   // float(0.01) < 0.01: same set of floats as the double compare
                     float wgt = fabsf(__fmul_rn(__fmul_rn(dstw, lev), dir));
@@ -485,18 +550,16 @@ __device__ __attribute__((always_inline)) inline int telea_pop_march(const Telea
                     else gix = nl ? __fsub_rn(vD, vB) : 0.f;
                     if (nd) giy = nu ? __fmul_rn(__fsub_rn(vE, vF), 2.0f) : __fsub_rn(vE, vC);
                     else giy = nu ? __fsub_rn(vG, vF) : 0.f;
-                    aIa = __fadd_rn(aIa, __fmul_rn(wgt, vC));
-                    aJx = __fsub_rn(aJx, __fmul_rn(wgt, __fmul_rn(gix, rx)));
-                    aJy = __fsub_rn(aJy, __fmul_rn(wgt, __fmul_rn(giy, ry)));
-                    aS = __fadd_rn(aS, wgt);
+                    aIa = __fmul_rn(wgt, vC);
+                    aJx = -__fmul_rn(wgt, __fmul_rn(gix, rx));
+                    aJy = -__fmul_rn(wgt, __fmul_rn(giy, ry));
+                    aS = wgt;
                 }
             }
+            const int nl = nn - n0 < 64 ? nn - n0 : 64;
+            Ia = wn_seq_sum_n(aIa, Ia, nl, lane); Jx = wn_seq_sum_n(aJx, Jx, nl, lane); Jy = wn_seq_sum_n(aJy, Jy, nl, lane); s = wn_seq_sum_n(aS, s, nl, lane);
         }
-        const float Ia = wn_dpp_sum(aIa), Jx = wn_dpp_sum(aJx), Jy = wn_dpp_sum(aJy), s = __fadd_rn(wn_dpp_sum(aS), 1.0e-20f);
-        // Ia/s + (Jx+Jy)/(sqrt(Jx^2+Jy^2) + 1e-20): the second term is a ratio in [-sqrt2, sqrt2]; OpenCV forms it in
-        // double, its float evaluation differs by < 2e-7 absolute before the final rounding to float
-        const float nrm = __fadd_rn(__fsqrt_rn(__fadd_rn(__fmul_rn(Jx, Jx), __fmul_rn(Jy, Jy))), 1.0e-20f);
-        const float val = __fadd_rn(__fdiv_rn(Ia, s), __fdiv_rn(__fadd_rn(Jx, Jy), nrm));
+        const float val = telea_estimate(Ia, Jx, Jy, s);
         if (lane == 0) { im[pi] = val; f[pi] = (uint8_t)(W_HOLE | W_BAND); }
         push(dist, pi);
     }

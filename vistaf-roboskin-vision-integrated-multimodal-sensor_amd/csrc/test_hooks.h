@@ -1,0 +1,18 @@
+/* Test-only entry points of libvistaf_ftp.so.  NOT part of the drop-in boundary (include/vistaf_ftp.h): nothing a caller of the
+ * path needs lives here.  The parity tests use them to run the fallback / opt-in kernels of a stage against the default ones and
+ * to read planes that the production path does not materialise. */
+#ifndef VISTAF_TEST_HOOKS_H
+#define VISTAF_TEST_HOOKS_H
+#include "../../include/vistaf_ftp.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* name: "inpaint_tier"  2 window march + whole-frame fallback (default), 1 whole-frame kernel only, 0 cluster front end first
+ *       "flood_tier"    2 batched pops (default), 1 one pop per step, 0 frontier scan
+ *       "chamfer_twopass" 1 forces the one-wave two-pass chamfer transform
+ *       "keep_planes"   1 also writes the float64 demodulated field of every frame ("field" of vistaf_ftp_get_intermediate) */
+int vistaf_ftp_test_set(vistaf_ftp_handle *hd, const char *name, int value);
+#ifdef __cplusplus
+}
+#endif
+#endif

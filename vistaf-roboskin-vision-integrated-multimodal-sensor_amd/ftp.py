@@ -226,6 +226,11 @@ class FtpSensor:
         torch.cuda.synchronize(self.device)
         return buf.view(dtype)
 
+    def _test_set(self, name: str, value: int):
+        """Test hook (csrc/test_hooks.h, not part of the boundary): select a fallback / opt-in kernel tier of a stage
+        ("inpaint_tier", "flood_tier", "chamfer_twopass") or keep debug planes ("keep_planes")."""
+        _lib.check(self._lib.vistaf_ftp_test_set(self._h, name.encode(), int(value)))
+
     def masks(self, index: int = 0) -> Dict[str, np.ndarray]:
         """The seven boolean crop masks of frame `index` of the last predict_batch, under the names the reference stores
         them with in height_map_bundle.npz (Code/shape_ftp.py:1898-1906)."""
