@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VISTAF_FTP_ABI_VERSION 1
+#define VISTAF_FTP_ABI_VERSION 2   /* 2: hole-stage constants in vistaf_ftp_config, vistaf_ftp_predict_pairs */
 
 /* error codes */
 #define VISTAF_OK 0
@@ -43,7 +43,7 @@ extern "C" {
 #define VISTAF_FRAME_OK 0
 #define VISTAF_FRAME_EMPTY_RELIABLE 1   /* upstream: main() logs and returns None (shape_ftp.py:1677-1679) */
 #define VISTAF_FRAME_QUEUE_OVERFLOW 2   /* internal work queue exhausted (never for valid sizes) */
-#define VISTAF_FRAME_HOLES_UNSUPPORTED 3/* non-finite height inside reliable: upstream hole inpaint (:1786) */
+#define VISTAF_FRAME_NO_CARRIER 3       /* pair mode: no usable carrier peak in this sample's reference frame */
 
 /* input frame formats */
 #define VISTAF_FMT_GRAY_U8 0    /* [B,h,w] uint8 (cv2.cvtColor(...,BGR2GRAY) already applied) */
@@ -86,7 +86,9 @@ typedef struct vistaf_ftp_config {
     int32_t n_fft_peaks;                /* :168 12   */
     int32_t plane_order_for_removal;    /* :212 1    */
     int32_t irls_iters;                 /* :1100 6   */
-    int32_t reserved0;
+    int32_t hole_neighborhood_px;       /* :140 11   (only read when reliable_smooth_sigma_px == 0, see :1770-1801) */
+    int32_t hole_min_dist_px;           /* :142 4    */
+    int32_t inpaint_radius;             /* :144 5    */
     double pre_blur_sigma_px;           /* :38  1.5  */
     double amp_valid_percentile;        /* :90  25   */
     double quality_smooth_sigma_px;     /* :91  6    */
@@ -105,6 +107,7 @@ typedef struct vistaf_ftp_config {
     double irls_c;                      /* :1100 4.685 */
     double grating_pitch_mm;            /* force_sensor.py:33  2.0  */
     double depth_eps_mm;                /* force_sensor.py:34  0.01 */
+    double hole_known_fraction;         /* :141 0.70 */
 } vistaf_ftp_config;
 
 /* per-frame scalar record written by predict_batch: d_scalars[b*VISTAF_NSCALARS + i] (double) */

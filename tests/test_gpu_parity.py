@@ -422,3 +422,67 @@ def test_sixty_four_more_frames_against_oracle(pkg, cal):
         assert np.array_equal(qual[b][rs["roi"]], o["inter"]["quality"][rs["roi"]]), b   # the plane the reliable mask is thresholded from: same bits
         assert np.array_equal(rel[b], o["reliable"]), b
         _check_frame(out, b, o, n)
+
+
+def _moat_frame(pkg, n, seed, ref=False, ir=18, mw=12, neck=7, ox=40):
+    """A fringe frame whose contrast drops to 8 % on a ring ("moat") around an island that stays connected to the rest through a narrow
+    corridor: the reliable mask is ONE component after largest_connected_component, and erode_by_distance then cuts the corridor, so the
+    quality-guided flood never reaches the island (shape_ftp.py:770-773, :1043-1080)."""
+    rng = np.random.default_rng(seed)
+    p = pkg.synth.NATIVE_PERIOD_PX * n / pkg.synth.NATIVE_CROP
+    cx, cy, r = pkg.synth.roi_circle(n)
+    yy, xx = np.mgrid[0:n, 0:n].astype(np.float64)
+    s = 1.0 + 0.15 * np.cos(np.pi * np.sqrt((xx - cx) ** 2 + (yy - cy) ** 2) / r)
+    contrast, phi = np.ones((n, n)), 0.0
+    if not ref:
+        d = np.sqrt((xx - (cx + ox)) ** 2 + (yy - cy) ** 2)
+        contrast[(d >= ir) & (d <= ir + mw) & ~((np.abs(yy - cy) <= neck / 2.0) & (xx < cx + ox))] = 0.08
+        phi = -0.7 * np.exp(-((xx - cx + 20) ** 2 + (yy - cy - 10) ** 2) / (2 * (0.12 * n) ** 2))
+    img = 128.0 * s * (0.55 + 0.35 * contrast * np.cos(2 * np.pi * xx / p + phi)) + rng.normal(0, 2.0, (n, n))
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def test_internal_holes_branch_without_reliable_smoothing(pkg, cal):
+    """§8(a) row 15: compute_internal_holes_within_mask + inpaint_only_mask (shape_ftp.py:1153-1204, :1770-1801).  The branch is only live
+    with RELIABLE_SMOOTH_SIGMA_PX = 0 (a positive sigma leaves every reliable pixel finite).  Frames whose reliable mask falls apart in
+    erode_by_distance leave an island the flood never reaches: NaN inside reliable -> hole candidates (box-filter fraction, chamfer
+    distance) -> Telea fill (radius 5) of the candidates, the rest leaves output_reliable.  Hole constants chosen so that all three
+    outcomes (filled, dropped, untouched) occur; a wider demodulation patch (20 bins) resolves the 12-pixel moat."""
+    n = 224
+    cfg = pkg.FtpConfig.scaled(n)
+    cfg.reliable_smooth_sigma_px = 0.0
+    cfg.reliable_edge_margin_px = 7
+    cfg.valid_close_kernel = 3
+    cfg.patch_half_width_bins = 20
+    cfg.hole_neighborhood_px, cfg.hole_known_fraction, cfg.hole_min_dist_px = 71, 0.25, 1
+    ref = _moat_frame(pkg, n, 99999, ref=True)
+    frames = np.stack([_moat_frame(pkg, n, 7), _moat_frame(pkg, n, 8, ir=16, mw=12, neck=9), pkg.synth.deformed_frame(n, 3)])
+    nb = len(frames)
+    _, sensor = _sensor(pkg, cal, n, cfg, nb, ref=ref)
+    out = sensor.predict_batch(frames)
+    torch.cuda.synchronize()
+    rs = O.make_reference_state(ref, *pkg.synth.roi_circle(n), cfg)
+    holes_g = sensor.intermediate("hole_cand", nb, torch.uint8).cpu().numpy().reshape(nb, n, n) != 0
+    rel_g = sensor.intermediate("reliable", nb, torch.uint8).cpu().numpy().reshape(nb, n, n) != 0
+    seen_filled = seen_dropped = 0
+    for b in range(nb):
+        o = O.process_frame(frames[b], rs, cfg, *cal, keep_intermediates=True)
+        assert np.array_equal(rel_g[b], o["reliable"])
+        assert np.array_equal(holes_g[b], o["hole_candidates"])
+        _check_frame(out, b, o, n)                                   # includes output_reliable == oracle's, map within 1e-4 of the peak
+        seen_filled += int(o["hole_candidates"].sum())
+        seen_dropped += int((o["reliable"] & ~o["output_reliable_crop"]).sum())
+        if b == 0:
+            assert np.array_equal(sensor.masks(0)["hole_candidates"], o["hole_candidates"])
+    assert seen_filled > 100 and seen_dropped > 10                   # the branch really ran: pixels filled AND pixels dropped
+    # with the smoothing on, the same frames never enter the branch: output_reliable == reliable upstream and here
+    cfg2 = pkg.FtpConfig.scaled(n)
+    cfg2.reliable_edge_margin_px, cfg2.valid_close_kernel, cfg2.patch_half_width_bins = 7, 3, 20
+    _, s2 = _sensor(pkg, cal, n, cfg2, nb, ref=ref)
+    out2 = s2.predict_batch(frames)
+    torch.cuda.synchronize()
+    rs2 = O.make_reference_state(ref, *pkg.synth.roi_circle(n), cfg2)
+    for b in range(nb):
+        o2 = O.process_frame(frames[b], rs2, cfg2, *cal)
+        assert not o2["hole_candidates"].any() and np.array_equal(o2["output_reliable_crop"], o2["reliable"])
+        _check_frame(out2, b, o2, n)

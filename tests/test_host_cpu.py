@@ -34,13 +34,12 @@ def test_default_config_is_the_reference_constants(pkg):
     assert pkg._lib.load().vistaf_ftp_default_config(ctypes.byref(cc)) == 0
     py = pkg.FtpConfig.as_shipped()
     for name in pkg._lib._INT_FIELDS + pkg._lib._DBL_FIELDS:
-        if name == "reserved0":
-            continue
         assert getattr(cc, name) == getattr(py, name), name
     # spot values straight from Code/shape_ftp.py:27-218
     assert (cc.fft_pad_px, cc.apod_taper_px, cc.frontier_zero_band_px, cc.illum_sigma_px) == (96, 120, 200, 45.0)
     assert (cc.dilate_kernel_size, cc.dilate_iters, cc.contact_percentile, cc.amp_valid_percentile) == (15, 2, 92.0, 25.0)
-    assert ctypes.sizeof(pkg._lib.CConfig) == 20 * 4 + 18 * 8
+    assert (cc.hole_neighborhood_px, cc.hole_min_dist_px, cc.inpaint_radius, cc.hole_known_fraction) == (11, 4, 5, 0.70)   # :140-144
+    assert ctypes.sizeof(pkg._lib.CConfig) == 22 * 4 + 19 * 8 and pkg._lib.load().vistaf_ftp_abi_version() == 2
 
 
 def test_scaled_constants(pkg):

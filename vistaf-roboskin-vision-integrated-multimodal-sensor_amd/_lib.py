@@ -15,7 +15,7 @@ NSCALARS = 16
 NREFINFO = 8
 
 FMT_GRAY_U8, FMT_BGR_U8, FMT_GRAY_F16, FMT_BGR_F16 = 0, 1, 2, 3
-FRAME_OK, FRAME_EMPTY_RELIABLE, FRAME_QUEUE_OVERFLOW, FRAME_HOLES_UNSUPPORTED = 0, 1, 2, 3
+FRAME_OK, FRAME_EMPTY_RELIABLE, FRAME_QUEUE_OVERFLOW, FRAME_NO_CARRIER = 0, 1, 2, 3
 CURVE_TYPES = {"linear0": 0, "linear": 1, "poly2": 2, "sat_exp": 3, "growth": 4, "hinge_saturating": 5}
 
 EXPORTS = [
@@ -41,13 +41,13 @@ _INT_FIELDS = [
     "patch_half_width_bins", "dc_exclusion", "fft_pad_px", "roi_erode_px", "apod_taper_px", "reliable_edge_margin_px",
     "poly_order", "frontier_zero_band_px", "valid_close_kernel", "valid_close_iters", "bad_pixel_enable",
     "bad_dilate_ksize", "bad_dilate_iters", "bad_inpaint_radius", "dilate_kernel_size", "dilate_iters", "n_fft_peaks",
-    "plane_order_for_removal", "irls_iters", "reserved0",
+    "plane_order_for_removal", "irls_iters", "hole_neighborhood_px", "hole_min_dist_px", "inpaint_radius",
 ]
 _DBL_FIELDS = [
     "pre_blur_sigma_px", "amp_valid_percentile", "quality_smooth_sigma_px", "reliable_smooth_sigma_px", "illum_sigma_px",
     "bad_intensity_percentile", "bad_gradient_percentile", "contact_core_percentile", "contact_percentile",
     "min_contact_frac", "max_contact_frac", "unreliable_smooth_sigma_px", "contact_blob_min_peak_mm",
-    "contact_blob_min_peak_rel_frac", "peak_max_dy_from_center", "irls_c", "grating_pitch_mm", "depth_eps_mm",
+    "contact_blob_min_peak_rel_frac", "peak_max_dy_from_center", "irls_c", "grating_pitch_mm", "depth_eps_mm", "hole_known_fraction",
 ]
 
 

@@ -47,7 +47,7 @@ class FtpConfig:
     irls_c: float = 4.685
     grating_pitch_mm: float = 2.0
     depth_eps_mm: float = 0.01
-    # not part of the C struct (the GPU path asserts the hole stage is never entered)
+    # hole stage (Code/shape_ftp.py:140-144): only reached when reliable_smooth_sigma_px == 0 (:1770-1801)
     hole_neighborhood_px: int = 11
     hole_known_fraction: float = 0.70
     hole_min_dist_px: int = 4

@@ -80,6 +80,8 @@ struct vistaf_ftp_handle {
     double2 *field, *patch;
     double2 *tmpT;
     uint8_t *bad0, *bad1, *rel0, *rel1, *rel2, *reliable, *contact, *contact_d, *background, *cand, *kept;
+    uint8_t *out_rel = nullptr, *hole_cand = nullptr;      // hole stage only (reliable_smooth_sigma_px == 0)
+    float *hole_med = nullptr, *hole_fill = nullptr;
     int32_t *labels, *area, *rowdist, *parent;
     unsigned int *peak_bits;
     uint16_t *morph_pre;
@@ -154,9 +156,11 @@ bool chamfer_ball(float margin, RowSpanSE *se)
     return true;
 }
 
-int make_se(int k, RowSpanSE *se)
+// cv2.getStructuringElement(MORPH_ELLIPSE, (k, k)), anchor at (k/2, k/2).  force_odd: the callers that first do `max(3, k | 1)`
+// (shape_ftp.py:641-644, :756-758); the contact dilation passes DILATE_KERNEL_SIZE as it is (:1734), even sizes included.
+int make_se(int k, RowSpanSE *se, bool force_odd = true)
 {
-    k = std::max(3, k | 1);
+    if (force_odd) k = std::max(3, k | 1);
     if (k > 33) return fail(VISTAF_E_INVALID, "structuring element larger than 33");
     se->k = k;
     int r = k / 2, c = k / 2;
@@ -272,6 +276,7 @@ int vistaf_ftp_default_config(vistaf_ftp_config *c)
     c->contact_percentile = 92.0; c->min_contact_frac = 0.002; c->max_contact_frac = 0.40; c->unreliable_smooth_sigma_px = 9.0;
     c->contact_blob_min_peak_mm = 0.1; c->contact_blob_min_peak_rel_frac = 1.0 / 3.0; c->peak_max_dy_from_center = 0.12;
     c->irls_c = 4.685; c->grating_pitch_mm = 2.0; c->depth_eps_mm = 0.01;
+    c->hole_neighborhood_px = 11; c->hole_min_dist_px = 4; c->inpaint_radius = 5; c->hole_known_fraction = 0.70;
     return 0;
 }
 
@@ -338,7 +343,14 @@ int vistaf_ftp_create(const vistaf_ftp_config *cfg, int h, int w, int cx, int cy
     {   // cv2.getStructuringElement(ELLIPSE, (k,k)) with k as given (shape_ftp.py:1734)
         int k = cfg->dilate_kernel_size;
         if (k < 1 || k > 33) { vistaf_ftp_destroy(hd); return fail(VISTAF_E_INVALID, "dilate_kernel_size out of range"); }
-        TRY(make_se(k, &hd->se_contact));
+        TRY(make_se(k, &hd->se_contact, false));
+    }
+    if (!(cfg->reliable_smooth_sigma_px > 0)) {     // the hole stage is live (shape_ftp.py:1770-1801)
+        if (cfg->hole_neighborhood_px < 1 || cfg->hole_neighborhood_px > 255 || cfg->hole_min_dist_px < 0 || cfg->inpaint_radius < 1 ||
+            !(cfg->hole_known_fraction >= 0.0)) {
+            vistaf_ftp_destroy(hd);
+            return fail(VISTAF_E_INVALID, "hole-stage constants out of range");
+        }
     }
     // workspace
 #define PLANE(T, name) TRY(dalloc(hd, &hd->name, n, #name, (size_t)P * sizeof(T)))
@@ -349,6 +361,7 @@ int vistaf_ftp_create(const vistaf_ftp_config *cfg, int h, int w, int cx, int cy
     PLANE(double2, field);
     PLANE(uint8_t, bad0); PLANE(uint8_t, bad1); PLANE(uint8_t, rel0); PLANE(uint8_t, rel1); PLANE(uint8_t, rel2); PLANE(uint8_t, reliable);
     PLANE(uint8_t, contact); PLANE(uint8_t, contact_d); PLANE(uint8_t, background); PLANE(uint8_t, cand); PLANE(uint8_t, kept);
+    if (!(cfg->reliable_smooth_sigma_px > 0)) { PLANE(uint8_t, out_rel); PLANE(uint8_t, hole_cand); }
     PLANE(int32_t, labels); PLANE(int32_t, area); PLANE(int32_t, rowdist); PLANE(int32_t, parent);
     PLANE(unsigned int, peak_bits);
     PLANE(uint16_t, morph_pre);
@@ -377,6 +390,7 @@ int vistaf_ftp_create(const vistaf_ftp_config *cfg, int h, int w, int cx, int cy
     TRY(dalloc(hd, &hd->contact_count, mb)); TRY(dalloc(hd, &hd->bg_count, mb)); TRY(dalloc(hd, &hd->bad_count, mb));
     TRY(dalloc(hd, &hd->flipped, mb)); TRY(dalloc(hd, &hd->gmax, mb)); TRY(dalloc(hd, &hd->status, mb));
     TRY(dalloc(hd, &hd->scalars, mb * VISTAF_NSCALARS));
+    TRY(dalloc(hd, &hd->hole_med, mb)); TRY(dalloc(hd, &hd->hole_fill, mb));
     hd->named["mu"] = {hd->mu, sizeof(float)}; hd->named["thr_hi"] = {hd->thr_hi, sizeof(float)}; hd->named["thr_g"] = {hd->thr_g, sizeof(float)};
     hd->named["coef"] = {hd->coef, 6 * sizeof(float)}; hd->named["thr3"] = {hd->thr3, 3 * sizeof(float)};
     hd->named["core_thr"] = {hd->core_thr, sizeof(float)}; hd->named["core_med"] = {hd->core_med, sizeof(float)};
@@ -548,10 +562,11 @@ int vistaf_ftp_predict_batch(vistaf_ftp_handle *hd, const void *d_frames, int fo
     // ---- plane removal + two-pass detrend (shape_ftp.py:1706, :1716-1751)
     if (timed) hipEventRecord(hd->ev[ST_DETREND], st);
     if (c.plane_order_for_removal > 0)
-        launch_robust_polyfit(hd->unwrapped, hd->reliable, c.plane_order_for_removal, c.irls_iters, (float)c.irls_c, 500, hd->coef, hd->phase1, B, h, w, st);
+        // debug_ramp gates on the reliable count, NaN pixels included (:1364-1366), robust_polyfit2d on 200 finite samples (:1103)
+        launch_robust_polyfit(hd->unwrapped, hd->reliable, c.plane_order_for_removal, c.irls_iters, (float)c.irls_c, 200, 500, hd->coef, hd->phase1, B, h, w, st);
     else   // no debug_ramp (the constants of Code/phase_to_height.py): the unwrapped phase goes to the detrend as it is
         HIPCHK(hipMemcpyAsync(hd->phase1, hd->unwrapped, (size_t)B * P * sizeof(float), hipMemcpyDeviceToDevice, st));
-    launch_robust_polyfit(hd->phase1, hd->reliable, c.poly_order, c.irls_iters, (float)c.irls_c, 200, hd->coef, hd->resid0, B, h, w, st);
+    launch_robust_polyfit(hd->phase1, hd->reliable, c.poly_order, c.irls_iters, (float)c.irls_c, 200, 0, hd->coef, hd->resid0, B, h, w, st);
     launch_select(hd->resid0, hd->reliable, (size_t)P, nullptr, true, hd->req_contact, 3, hd->thr3, nullptr, B, P, st);
     launch_contact_mask(hd->resid0, hd->reliable, hd->thr3, hd->rel_count, hd->contact_count, (float)c.min_contact_frac, (float)c.max_contact_frac,
                         hd->contact, hd->thr_used, B, P, st);
@@ -572,20 +587,42 @@ int vistaf_ftp_predict_batch(vistaf_ftp_handle *hd, const void *d_frames, int fo
         }
     }
     launch_background(hd->reliable, hd->contact_d, hd->rel_count, hd->bg_count, hd->background, B, P, st);
-    launch_robust_polyfit(hd->phase1, hd->background, c.poly_order, c.irls_iters, (float)c.irls_c, 200, hd->coef, hd->detr, B, h, w, st);
+    launch_robust_polyfit(hd->phase1, hd->background, c.poly_order, c.irls_iters, (float)c.irls_c, 200, 0, hd->coef, hd->detr, B, h, w, st);
     launch_select(hd->detr, hd->background, (size_t)P, nullptr, false, hd->req_med, 1, hd->bg_med, nullptr, B, P, st);
 
     // ---- reliable-only smoothing + sign flip (shape_ftp.py:1753-1768)
     if (timed) hipEventRecord(hd->ev[ST_SMOOTH_FLIP], st);
-    launch_sub_scalar_mask(hd->detr, hd->bg_med, hd->reliable, hd->z0, hd->mplane, B, P, st);
-    if (hd->g_rel.k) {
+    const bool smooth_rel = hd->g_rel.k > 0;
+    if (smooth_rel) {
+        launch_sub_scalar_mask(hd->detr, hd->bg_med, hd->reliable, hd->z0, hd->mplane, B, P, st);
         blur(hd, hd->z0, hd->num, hd->g_rel, B, st);
         blur(hd, hd->mplane, hd->den, hd->g_rel, B, st);
         launch_div_planes(hd->num, hd->den, hd->hmap, B, P, st);
-    } else HIPCHK(hipMemcpyAsync(hd->hmap, hd->z0, (size_t)B * P * sizeof(float), hipMemcpyDeviceToDevice, st));
+    } else launch_zeroed_keep_nan(hd->detr, hd->bg_med, hd->reliable, hd->hmap, B, P, st);      // NaN stays NaN: the hole stage below is live
     launch_select(hd->hmap, hd->reliable, (size_t)P, nullptr, false, hd->req_core, 1, hd->core_thr, nullptr, B, P, st);
     launch_select(hd->hmap, hd->reliable, (size_t)P, hd->core_thr, false, hd->req_med, 1, hd->core_med, nullptr, B, P, st);
     launch_core_flip(hd->hmap, hd->core_med, hd->flipped, B, P, st);
+
+    // ---- internal holes of the reliable region (shape_ftp.py:1770-1801): with the smoothing every reliable pixel is finite here and
+    // upstream's compute_internal_holes_within_mask returns at its first test; without it the unreached pixels are NaN
+    const uint8_t *orel = hd->reliable;                      // output_reliable (:1801)
+    if (!smooth_rel) {
+        const int ksz = std::max(3, c.hole_neighborhood_px | 1);
+        launch_chamfer(hd->reliable, false, hd->rowdist, hd->dist, B, h, w, c.hole_min_dist_px + 1, st, hd->tiers.chamfer_twopass != 0);
+        launch_hole_candidates(hd->hmap, hd->reliable, hd->dist, ksz, (float)c.hole_known_fraction, (float)c.hole_min_dist_px, hd->hole_cand, B, h, w, st);
+        launch_select(hd->hmap, hd->reliable, (size_t)P, nullptr, false, hd->req_med, 1, hd->hole_med, nullptr, B, P, st);
+        launch_hole_tmp(hd->hmap, hd->reliable, hd->hole_cand, hd->hole_med, hd->z0, B, P, st);
+        launch_select(hd->z0, hd->reliable, (size_t)P, nullptr, false, hd->req_med, 1, hd->hole_fill, nullptr, B, P, st);
+        launch_hole_zin(hd->z0, hd->hole_fill, B, P, st);
+        {
+            const int range = std::min(100, std::max(1, cv_round((double)c.inpaint_radius)));
+            const int32_t *only = nullptr;
+            if (hd->tiers.inpaint != 1) only = launch_inpaint_window(hd->z0, hd->hole_cand, range, hd->inpaint_win_scratch, B, h, w, st, nullptr);
+            launch_inpaint_telea(hd->z0, hd->hole_cand, range, hd->inpaint_scratch, hd->status, only, B, h, w, st);
+        }
+        launch_hole_merge(hd->hmap, hd->reliable, hd->hole_cand, hd->z0, hd->out_rel, B, P, st);
+        orel = hd->out_rel;
+    }
 
     // ---- frontier taper, composition, unreliable-region smoothing, clamp (shape_ftp.py:1770-1841)
     if (timed) hipEventRecord(hd->ev[ST_COMPOSE], st);
@@ -593,11 +630,11 @@ int vistaf_ftp_predict_batch(vistaf_ftp_handle *hd, const void *d_frames, int fo
     float band = (float)c.frontier_zero_band_px;
     // both distance transforms of the reliable mask (to its outside for the taper, to its inside for the final blend) in one launch; the
     // second one lands in planes that are idle at this point (`area` as the integer temporary, `depth` -- written by to_mm below)
-    if (use_band) launch_chamfer_pair(hd->reliable, hd->rowdist, hd->dist, hd->area, hd->depth, B, h, w, c.frontier_zero_band_px + 2, st, hd->tiers.chamfer_twopass != 0);
+    if (use_band) launch_chamfer_pair(orel, hd->rowdist, hd->dist, hd->area, hd->depth, B, h, w, c.frontier_zero_band_px + 2, st, hd->tiers.chamfer_twopass != 0);
     else HIPCHK(hipMemsetAsync(hd->dist, 0x7f, (size_t)B * P * sizeof(float), st));   // huge distance: taper weight 1
-    launch_frontier_compose(hd->hmap, hd->reliable, hd->roi, hd->dist, use_band ? band : 1.0f, hd->z0f, hd->status, B, P, st);
+    launch_frontier_compose(hd->hmap, orel, hd->roi, hd->dist, use_band ? band : 1.0f, hd->z0f, B, P, st);
     if (hd->g_unrel.k) blur(hd, hd->z0f, hd->snum, hd->g_unrel, B, st);
-    launch_finalize_unitless(hd->z0f, hd->g_unrel.k ? hd->snum : nullptr, hd->roi_den, hd->reliable, hd->roi, use_band ? hd->depth : hd->dist, band, use_band ? 1 : 0,
+    launch_finalize_unitless(hd->z0f, hd->g_unrel.k ? hd->snum : nullptr, hd->roi_den, orel, hd->roi, use_band ? hd->depth : hd->dist, band, use_band ? 1 : 0,
                              hd->unitless, B, P, st);
 
     // ---- unitless -> mm, blob filter (shape_ftp.py:1850-1873)
@@ -613,7 +650,7 @@ int vistaf_ftp_predict_batch(vistaf_ftp_handle *hd, const void *d_frames, int fo
     pp.mm_per_px = hd->mm_per_px; pp.depth_eps_mm = c.depth_eps_mm; pp.period_px = hd->period; pp.force_curve = hd->fcurve;
     launch_tail(hd->depth, nullptr, hd->unitless, hd->roi, pp, hd->scalars, VISTAF_NSCALARS, nullptr, B, P, st);
     launch_fill_scalars(hd->scalars, VISTAF_NSCALARS, hd->rel_count, hd->flipped, hd->amp_thr, hd->thr_used, hd->bg_med, hd->bad_count, B, st);
-    launch_copy_out(hd->depth, hd->reliable, hd->status, d_height_mm, d_reliable, B, P, st);
+    launch_copy_out(hd->depth, orel, hd->status, d_height_mm, d_reliable, B, P, st);
     if (d_scalars) HIPCHK(hipMemcpyAsync(d_scalars, hd->scalars, sizeof(double) * VISTAF_NSCALARS * B, hipMemcpyDeviceToDevice, st));
     if (d_status) HIPCHK(hipMemcpyAsync(d_status, hd->status, sizeof(int32_t) * B, hipMemcpyDeviceToDevice, st));
     if (timed) {

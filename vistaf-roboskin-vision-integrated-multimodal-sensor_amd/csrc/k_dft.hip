@@ -12,6 +12,7 @@
 // to the same float32 as the oracle's (oracle/ftp_oracle.py FFT_COMPLEX128) and every threshold downstream of them
 // (quality >= p25) sees the same plane.  Tables may be per frame (tab_stride != 0: the uncached-pair mode, where
 // every sample carries its own carrier) or shared by the batch (0).
+#include <algorithm>
 #include "kernels.hpp"
 
 namespace vf {
@@ -67,26 +68,26 @@ __global__ void k_dft_fwd2(const double2 *__restrict__ T, const double2 *__restr
 {
     size_t b = blockIdx.x;
     const double2 *Ey = Ey_all + b * ey_stride;
-    int t = threadIdx.x;
-    if (t >= ph * pw) return;
-    int a = t / pw, c = t % pw;
     const double2 *Tb = T + b * (size_t)h * pw;
-    double ar = 0.0, ai = 0.0;
-    // one workgroup per frame: the loads of eight rows are issued together (the loop was one memory round trip per row)
-    int y = 0;
-    for (; y + 8 <= h; y += 8) {
-        double2 e[8], v[8];
+    for (int t = threadIdx.x; t < ph * pw; t += blockDim.x) {       // one pass for patches up to 32 x 32 bins
+        int a = t / pw, c = t % pw;
+        double ar = 0.0, ai = 0.0;
+        // one workgroup per frame: the loads of eight rows are issued together (the loop was one memory round trip per row)
+        int y = 0;
+        for (; y + 8 <= h; y += 8) {
+            double2 e[8], v[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) { e[k] = Ey[(size_t)a * h + y + k]; v[k] = Tb[(size_t)(y + k) * pw + c]; }
+            for (int k = 0; k < 8; k++) { e[k] = Ey[(size_t)a * h + y + k]; v[k] = Tb[(size_t)(y + k) * pw + c]; }
 #pragma unroll
-        for (int k = 0; k < 8; k++) cmac(ar, ai, e[k].x, e[k].y, v[k].x, v[k].y);
+            for (int k = 0; k < 8; k++) cmac(ar, ai, e[k].x, e[k].y, v[k].x, v[k].y);
+        }
+        for (; y < h; y++) {
+            const double2 e = Ey[(size_t)a * h + y], v = Tb[(size_t)y * pw + c];
+            cmac(ar, ai, e.x, e.y, v.x, v.y);
+        }
+        const double wv = (double)win[t];
+        patch[b * (size_t)pstride + t] = make_double2(ar * wv, ai * wv);
     }
-    for (; y < h; y++) {
-        const double2 e = Ey[(size_t)a * h + y], v = Tb[(size_t)y * pw + c];
-        cmac(ar, ai, e.x, e.y, v.x, v.y);
-    }
-    const double wv = (double)win[t];
-    patch[b * (size_t)pstride + t] = make_double2(ar * wv, ai * wv);
 }
 
 void launch_dft_forward(const float *iw, const float *mu, const double2 *Ex, const double2 *Ey, size_t tab_stride_x, size_t tab_stride_y,
@@ -99,7 +100,7 @@ void launch_dft_forward(const float *iw, const float *mu, const double2 *Ex, con
     if (rb < 1) rb = 1;
     dim3 g1((h + rb * DFT_RR - 1) / (rb * DFT_RR), B);
     hipLaunchKernelGGL(k_dft_fwd1, g1, dim3(256), (size_t)rb * DFT_RR * w * sizeof(float), st, iw, mu, Ex, tab_stride_x, tmpT, h, w, pw, rb);
-    hipLaunchKernelGGL(k_dft_fwd2, dim3(B), dim3(((ph * pw + 63) / 64) * 64), 0, st, (const double2 *)tmpT, Ey, tab_stride_y, win, patch, h, ph, pw,
+    hipLaunchKernelGGL(k_dft_fwd2, dim3(B), dim3(std::min(1024, ((ph * pw + 63) / 64) * 64)), 0, st, (const double2 *)tmpT, Ey, tab_stride_y, win, patch, h, ph, pw,
                        patch_stride);
 }
 

@@ -102,7 +102,7 @@ __device__ inline bool chol_solve(double (&A)[6][6], double (&rhs)[6])
 }
 
 __global__ __launch_bounds__(SEL_T) void k_robust_polyfit(const float *__restrict__ z_all, const uint8_t *__restrict__ mask_all, int order,
-                                                          int iters, float c, int min_count, float *__restrict__ coef_out,
+                                                          int iters, float c, int min_count, int min_mask_count, float *__restrict__ coef_out,
                                                           float *__restrict__ resid_all, int h, int w, uint32_t magic)
 {
     __shared__ SelShared sh;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit(const float *__restric
     // thread only ever touches the pixels tid, tid + 1024, ...: its own stores, so no fence is needed.
     float *zc = resid_all + b * (size_t)P;
     // the same pass counts the fitted pixels and finds the range of z (coefficients are still zero: r = z)
-    uint32_t cnt0 = 0;
+    uint32_t cnt0 = 0, cntm = 0;
     unsigned long long mn0 = ~0ull, mx0 = 0;
     {
         int p = tid;
@@ -140,6 +140,7 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit(const float *__restric
 #pragma unroll
             for (int u = 0; u < FIT_U; u++) {
                 const bool ok = mk[u] && finitef(zz[u]);
+                cntm += mk[u] != 0;
                 zc[p + u * SEL_T] = ok ? zz[u] : __uint_as_float(0x7fc00000u);
                 if (ok) { const uint32_t key = f2key(zz[u]); cnt0++; if (key < mn0) mn0 = key; if (key + 1ull > mx0) mx0 = key + 1ull; }
             }
@@ -147,6 +148,7 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit(const float *__restric
         for (; p < P; p += SEL_T) {
             const float zz = z[p];
             const bool ok = m[p] && finitef(zz);
+            cntm += m[p] != 0;
             zc[p] = ok ? zz : __uint_as_float(0x7fc00000u);
             if (ok) { const uint32_t key = f2key(zz); cnt0++; if (key < mn0) mn0 = key; if (key + 1ull > mx0) mx0 = key + 1ull; }
         }
@@ -161,13 +163,14 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit(const float *__restric
     {
         __syncthreads();
         n = block_sum<uint32_t>(cnt0, sh.wsum);
+        if (min_mask_count > 0) cntm = block_sum<uint32_t>(cntm, sh.wsum);
         mn0 = block_min_u64(mn0, sh.red64);
         mx0 = block_max_u64(mx0, sh.red64);
         zkmin = (uint32_t)mn0; zkmax = mx0 ? (uint32_t)(mx0 - 1) : 0;
         __syncthreads();
     }
     const float zmin = key2f(zkmin), zmax = key2f(zkmax);
-    const bool do_fit = (int)n >= min_count;
+    const bool do_fit = (int)n >= min_count && (min_mask_count <= 0 || (int)cntm >= min_mask_count);
 
     float csig = 1.f;      // c * sigma of the previous iteration
     for (int it = 0; do_fit && it < iters; it++) {
@@ -286,13 +289,13 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit(const float *__restric
     }
 }
 
-// min_count: 200 upstream (:1103); 500 for the debug_ramp call (shape_ftp.py:1365)
-void launch_robust_polyfit(const float *z, const uint8_t *mask, int order, int iters, float c, int min_count, float *coef_out,
+// min_count: 200 fitted pixels upstream (:1103); min_mask_count: 500 mask pixels for the debug_ramp call (shape_ftp.py:1364-1366), else 0
+void launch_robust_polyfit(const float *z, const uint8_t *mask, int order, int iters, float c, int min_count, int min_mask_count, float *coef_out,
                            float *resid_out, int B, int h, int w, hipStream_t st)
 {
     // i / w == umulhi(i, magic) for every i < h * w as long as h * w * w < 2^32
     const uint32_t magic = ((unsigned long long)h * w * w < 0x100000000ull) ? (uint32_t)(0x100000000ull / (unsigned)w) + 1u : 0u;
-    hipLaunchKernelGGL(k_robust_polyfit, dim3(B), dim3(SEL_T), 0, st, z, mask, order, iters, c, min_count, coef_out, resid_out, h, w, magic);
+    hipLaunchKernelGGL(k_robust_polyfit, dim3(B), dim3(SEL_T), 0, st, z, mask, order, iters, c, min_count, min_mask_count, coef_out, resid_out, h, w, magic);
 }
 
 }  // namespace vf

@@ -128,7 +128,7 @@ void launch_core_flip(float *hmap, const float *core_med, int *flipped, int B, i
 // ---- frontier taper inside reliable + composition (shape_ftp.py:1770-1818, :1287-1318) -----------
 // z0 = height_final with NaN -> 0: 0 on unreliable ROI / outside ROI, tapered height on reliable.
 __global__ void k_frontier_compose(const float *__restrict__ hmap, const uint8_t *__restrict__ reliable, const uint8_t *__restrict__ roi,
-                                   const float *__restrict__ dist_in, float band, float *__restrict__ z0, int32_t *__restrict__ status, int P)
+                                   const float *__restrict__ dist_in, float band, float *__restrict__ z0, int P)
 {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     size_t b = blockIdx.y;
@@ -136,8 +136,7 @@ __global__ void k_frontier_compose(const float *__restrict__ hmap, const uint8_t
     size_t i = b * (size_t)P + p;
     float v = 0.f;
     if (reliable[i] && roi[p]) {
-        float hgt = hmap[i];
-        if (!finitef(hgt)) { status[b] = 3; hgt = 0.f; }   // upstream would inpaint a hole here (:1786-1799)
+        const float hgt = hmap[i];        // finite: `reliable` is output_reliable = reliable & isfinite(height) (:1801)
         float de = fmaxf(__fsub_rn(dist_in[i], 1.0f), 0.0f);
         float t = __fdiv_rn(de, fmaxf(1e-6f, band));
         t = fminf(fmaxf(t, 0.0f), 1.0f);
@@ -147,9 +146,9 @@ __global__ void k_frontier_compose(const float *__restrict__ hmap, const uint8_t
     z0[i] = v;
 }
 void launch_frontier_compose(const float *hmap, const uint8_t *reliable, const uint8_t *roi, const float *dist_in, float band,
-                             float *hfinal_z0, int32_t *status, int B, int P, hipStream_t st)
+                             float *hfinal_z0, int B, int P, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_frontier_compose, dim3((P + 255) / 256, B), dim3(256), 0, st, hmap, reliable, roi, dist_in, band, hfinal_z0, status, P);
+    hipLaunchKernelGGL(k_frontier_compose, dim3((P + 255) / 256, B), dim3(256), 0, st, hmap, reliable, roi, dist_in, band, hfinal_z0, P);
 }
 
 // unreliable ROI <- masked blur, outside band <- 0, clamp positives, NaN outside ROI (:1820-1841)

@@ -106,8 +106,17 @@ void launch_unwrap(const float *wrapped, const float *quality, const uint8_t *ma
                    hipEvent_t ev_flood = nullptr, int flood_tier = 2);
 
 // ---- k_fit.hip --------------------------------------------------------------------------------
-void launch_robust_polyfit(const float *z, const uint8_t *mask, int order, int iters, float c, int min_count, float *coef_out,
+// min_count: fitted (mask & finite) pixels needed (:1103); min_mask_count: mask pixels needed, NaN included (debug_ramp's own gate, :1364)
+void launch_robust_polyfit(const float *z, const uint8_t *mask, int order, int iters, float c, int min_count, int min_mask_count, float *coef_out,
                            float *resid_out, int B, int h, int w, hipStream_t st);
+
+// ---- k_holes.hip (hole stage, shape_ftp.py:1153-1204, :1770-1801; live only when reliable_smooth_sigma_px == 0) ----------------------
+void launch_zeroed_keep_nan(const float *detr, const float *bg_med, const uint8_t *reliable, float *hmap, int B, int P, hipStream_t st);
+void launch_hole_candidates(const float *hmap, const uint8_t *reliable, const float *dist, int ksize, float frac_thr, float min_dist, uint8_t *cand,
+                            int B, int h, int w, hipStream_t st);
+void launch_hole_tmp(const float *hmap, const uint8_t *reliable, const uint8_t *cand, const float *med, float *tmp, int B, int P, hipStream_t st);
+void launch_hole_zin(float *tmp_zin, const float *fill, int B, int P, hipStream_t st);
+void launch_hole_merge(float *hmap, const uint8_t *reliable, const uint8_t *cand, const float *zin, uint8_t *out_rel, int B, int P, hipStream_t st);
 
 // ---- k_post.hip -------------------------------------------------------------------------------
 struct PostParams {
@@ -123,7 +132,7 @@ void launch_sub_scalar_mask(const float *src, const float *scalar, const uint8_t
 void launch_div_planes(const float *num, const float *den, float *out, int B, int P, hipStream_t st);
 void launch_core_flip(float *hmap, const float *core_med, int *flipped, int B, int P, hipStream_t st);
 void launch_frontier_compose(const float *hmap, const uint8_t *reliable, const uint8_t *roi, const float *dist_in, float band,
-                             float *hfinal_z0, int32_t *status, int B, int P, hipStream_t st);
+                             float *hfinal_z0, int B, int P, hipStream_t st);
 void launch_finalize_unitless(const float *hfinal_z0, const float *smooth_num, const float *roi_den, const uint8_t *reliable,
                               const uint8_t *roi, const float *dist_out, float band, int use_band, float *unitless, int B, int P,
                               hipStream_t st);

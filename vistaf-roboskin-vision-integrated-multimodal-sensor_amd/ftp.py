@@ -246,9 +246,11 @@ class FtpSensor:
         yy, xx = np.ogrid[:self.h, :self.w]
         circ = ((xx - cx) ** 2 + (yy - cy) ** 2) <= r * r                                   # create_circular_mask (:437-440)
         reliable = plane("reliable")
+        # hole candidates exist only without the reliable-region smoothing (Code/shape_ftp.py:1770-1801); otherwise upstream stores zeros too
+        holes = plane("hole_cand") if not (self.config.reliable_smooth_sigma_px > 0) else np.zeros((self.h, self.w), dtype=bool)
         return {
             "roi_eroded": roi, "reliable": reliable, "output_reliable": last["output_reliable"][index].cpu().numpy().astype(bool), "circ_mask": circ,
-            "contact_kept_by_depth": plane("kept"), "hole_candidates": np.zeros((self.h, self.w), dtype=bool),
+            "contact_kept_by_depth": plane("kept"), "hole_candidates": holes,
             "contact_dilated": plane("contact_d"),
         }
 
