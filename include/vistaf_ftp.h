@@ -165,6 +165,17 @@ int vistaf_ftp_predict_batch(vistaf_ftp_handle *hd, const void *d_frames, int fo
                              float *d_height_mm, uint8_t *d_reliable, double *d_scalars,
                              int32_t *d_status, void *stream);
 
+/* Uncached pairs: sample b = (d_refs[b], d_defs[b]), both in `format`; every sample's reference frame is demodulated with its own
+ * carrier search and its deformed frame locked to that carrier -- what Code/height_to_force.py:384 does when it calls shape_ftp.main once
+ * per image (shape_ftp.py:1632-1653).  Needs no vistaf_ftp_set_reference.  Outputs as vistaf_ftp_predict_batch; d_status[b] =
+ * VISTAF_FRAME_NO_CARRIER when sample b's reference spectrum has no usable carrier peak.  Asynchronous on `stream`. */
+int vistaf_ftp_predict_pairs(vistaf_ftp_handle *hd, const void *d_refs, const void *d_defs, int format, int batch,
+                             float *d_height_mm, uint8_t *d_reliable, double *d_scalars, int32_t *d_status, void *stream);
+
+/* Reference-frame info of the samples of the last predict_pairs: out[b*VISTAF_NREFINFO + i], fields as
+ * vistaf_ftp_get_reference_info.  Synchronises `stream`. */
+int vistaf_ftp_get_pair_info(vistaf_ftp_handle *hd, int batch, double *out, void *stream);
+
 /* Copy a named intermediate plane of the last predict_batch (parity tests / debugging) into d_dst.
  * Returns the number of bytes per frame through *bytes_per_frame; d_dst may be NULL to query. */
 int vistaf_ftp_get_intermediate(vistaf_ftp_handle *hd, const char *name, void *d_dst, int batch,

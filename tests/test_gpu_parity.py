@@ -486,3 +486,39 @@ def test_internal_holes_branch_without_reliable_smoothing(pkg, cal):
         o2 = O.process_frame(frames[b], rs2, cfg2, *cal)
         assert not o2["hole_candidates"].any() and np.array_equal(o2["output_reliable_crop"], o2["reliable"])
         _check_frame(out2, b, o2, n)
+
+
+def test_uncached_pairs_128(pkg, cal):
+    """BASELINE configs[4] as SURVEY.md 8(d) restates it: (reference, deformed) PAIRS with the reference-frame demodulation NOT cached --
+    carrier search + reference demodulation per sample, as Code/height_to_force.py:384 runs shape_ftp.main per image.  128 pairs = the
+    per-GPU shard of 1024 / 8.  Every sample has its OWN reference frame (different noise realisation, two grating periods), checked
+    against O.make_reference_state + O.process_frame per pair at the strict bar."""
+    n, nb = 224, 128
+    cfg = pkg.FtpConfig.scaled(n)
+    periods = [pkg.synth.NATIVE_PERIOD_PX * n / pkg.synth.NATIVE_CROP, 11.3]
+    refs = np.stack([pkg.synth._base(n, 0.0, np.random.default_rng(770000 + b), periods[b % 2]) for b in range(nb)])
+    defs = np.stack([pkg.synth.deformed_frame(n, 4000 + b, config=3, period=periods[b % 2], amp_scale=1.0 + 0.5 * (b % 3)) for b in range(nb)])
+    sensor = pkg.FtpSensor(None, pkg.synth.roi_circle(n), cfg, cal[0], cal[1], cal[2], max_batch=nb, frame_shape=(n, n))
+    out = sensor.predict_pairs(refs, defs)
+    torch.cuda.synchronize()
+    info = sensor.pair_info(nb)
+    assert int((out["status"] != 0).sum()) == 0
+    for b in range(nb):
+        rs = O.make_reference_state(refs[b], *pkg.synth.roi_circle(n), cfg)
+        assert np.allclose(info[b]["peak_refined"], rs["demod"]["peak_refined"], rtol=0, atol=1e-9), b
+        _check_frame(out, b, O.process_frame(defs[b], rs, cfg, *cal), n)
+    # the same pairs through a session per reference (cached mode) give the same bits: one code path builds the tables of both modes
+    for b in (0, 1, 77):
+        _, s1 = _sensor(pkg, cal, n, cfg, 1, ref=refs[b])
+        o1 = s1.predict_batch(defs[b][None])
+        assert torch.equal(torch.nan_to_num(o1["height_map_mm"][0], nan=-7.0), torch.nan_to_num(out["height_map_mm"][b], nan=-7.0))
+        assert torch.equal(o1["scalars"][0], out["scalars"][b])
+    # a featureless reference frame (its "carrier" is rounding noise) must not disturb its neighbours in the batch
+    refs2, defs2 = refs[:4].copy(), defs[:4].copy()
+    refs2[2] = 90
+    o2 = sensor.predict_pairs(refs2, defs2)
+    torch.cuda.synchronize()
+    st = o2["status"].cpu().numpy()
+    assert (st[[0, 1, 3]] == 0).all() and st[2] in (0, 1, 3)
+    for b in (0, 1, 3):
+        assert torch.equal(torch.nan_to_num(o2["height_map_mm"][b], nan=-7.0), torch.nan_to_num(out["height_map_mm"][b], nan=-7.0))

@@ -20,7 +20,8 @@ CURVE_TYPES = {"linear0": 0, "linear": 1, "poly2": 2, "sat_exp": 3, "growth": 4,
 
 EXPORTS = [
     "vistaf_ftp_abi_version", "vistaf_ftp_last_error", "vistaf_ftp_default_config", "vistaf_ftp_create",
-    "vistaf_ftp_set_reference", "vistaf_ftp_get_reference_info", "vistaf_ftp_predict_batch",
+    "vistaf_ftp_set_reference", "vistaf_ftp_get_reference_info", "vistaf_ftp_predict_batch", "vistaf_ftp_predict_pairs",
+    "vistaf_ftp_get_pair_info",
     "vistaf_ftp_get_intermediate", "vistaf_ftp_stage_count", "vistaf_ftp_stage_name",
     "vistaf_ftp_enable_stage_timing", "vistaf_ftp_get_stage_times", "vistaf_ftp_destroy",
     "vistaf_depth_map_to_volume", "vistaf_predict_force_from_volume",
@@ -78,6 +79,8 @@ def load():
     lib.vistaf_ftp_set_reference.argtypes = [vp, vp, ci, vp]
     lib.vistaf_ftp_get_reference_info.argtypes = [vp, ctypes.POINTER(cd)]
     lib.vistaf_ftp_predict_batch.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp, vp]
+    lib.vistaf_ftp_predict_pairs.argtypes = [vp, vp, vp, ci, ci, vp, vp, vp, vp, vp]
+    lib.vistaf_ftp_get_pair_info.argtypes = [vp, ci, ctypes.POINTER(cd), vp]
     lib.vistaf_ftp_get_intermediate.argtypes = [vp, ctypes.c_char_p, vp, ci, ctypes.POINTER(ctypes.c_size_t), vp]
     lib.vistaf_ftp_stage_count.restype = ci
     lib.vistaf_ftp_stage_name.restype = ctypes.c_char_p

@@ -67,7 +67,7 @@ struct vistaf_ftp_handle {
     // uncached-pair mode (vistaf_ftp_predict_pairs): per-frame carriers, tables and reference fields, allocated on first use
     CarrierGeom *pgeom = nullptr;
     double2 *pEx = nullptr, *pEy = nullptr, *pGx = nullptr, *pGy = nullptr, *pcref = nullptr;
-    float *pamp_ref = nullptr;
+    float *pamp_ref = nullptr, *win_full = nullptr;
     bool pairs_ready = false;
     Tiers tiers;                                       // kernel tier selection (test hook; defaults = production kernels)
     bool keep_planes = false;                          // test hook: also write planes that only the parity tests read (float64 field)
@@ -490,28 +490,14 @@ int vistaf_ftp_get_reference_info(const vistaf_ftp_handle *hd, double *o)
     return 0;
 }
 
-int vistaf_ftp_predict_batch(vistaf_ftp_handle *hd, const void *d_frames, int format, int B, float *d_height_mm, uint8_t *d_reliable,
-                             double *d_scalars, int32_t *d_status, void *stream)
+// Everything after the demodulation (shape_ftp.py:1655-2037 + the force tail), shared by the session mode and the uncached-pair mode.
+// In: hd->amp-independent planes `prod` (amp_ref * amp_def) and `wrapped`.  pair_geom: per-frame carriers (pair mode) or null.
+static int post_demod(vistaf_ftp_handle *hd, int B, float *d_height_mm, uint8_t *d_reliable, double *d_scalars, int32_t *d_status,
+                      const CarrierGeom *pair_geom, hipStream_t st)
 {
-    if (!hd || !d_frames) return fail(VISTAF_E_INVALID, "null argument");
-    if (!hd->have_ref) return fail(VISTAF_E_STATE, "set_reference has not been called");
-    if (B < 1 || B > hd->maxB) return fail(VISTAF_E_STATE, "batch exceeds max_batch");
-    if (format < 0 || format > 3) return fail(VISTAF_E_INVALID, "bad frame format");
-    if (!(hd->period > 1e-12)) return fail(VISTAF_E_STATE, "Invalid estimated_grating_period_px");
-    hipStream_t st = (hipStream_t)stream;
     const vistaf_ftp_config &c = hd->cfg;
     int h = hd->h, w = hd->w, P = hd->P;
     bool timed = hd->timing;
-    if (timed && !hd->ev_made) { for (int i = 0; i <= ST_COUNT; i++) hipEventCreate(&hd->ev[i]); hd->ev_made = true; }
-    HIPCHK(hipMemsetAsync(hd->status, 0, sizeof(int32_t) * B, st));
-
-    preprocess(hd, d_frames, format, B, st, timed);
-
-    // ---- demodulation, carrier locked to the reference (shape_ftp.py:1643-1653, :1681-1689)
-    if (timed) hipEventRecord(hd->ev[ST_DEMOD], st);
-    launch_dft_forward(hd->iw, hd->mu, hd->Ex, hd->Ey, 0, 0, hd->win, hd->tmpT, hd->patch, hd->pmax * hd->pmax, B, h, w, hd->ph, hd->pw, st);
-    launch_dft_inverse(hd->patch, hd->pmax * hd->pmax, hd->Gx, hd->Gy, 0, 0, hd->tmpT, hd->keep_planes ? hd->field : nullptr, hd->amp, hd->cref,
-                       hd->amp_ref, 0, hd->prod, hd->wrapped, B, h, w, hd->ph, hd->pw, st);
 
     // ---- reliable mask (shape_ftp.py:739-775)
     if (timed) hipEventRecord(hd->ev[ST_RELIABLE], st);
@@ -648,6 +634,7 @@ int vistaf_ftp_predict_batch(vistaf_ftp_handle *hd, const void *d_frames, int fo
     if (timed) hipEventRecord(hd->ev[ST_TAIL], st);
     PostParams pp;
     pp.mm_per_px = hd->mm_per_px; pp.depth_eps_mm = c.depth_eps_mm; pp.period_px = hd->period; pp.force_curve = hd->fcurve;
+    pp.pair_geom = pair_geom; pp.grating_pitch_mm = c.grating_pitch_mm;
     launch_tail(hd->depth, nullptr, hd->unitless, hd->roi, pp, hd->scalars, VISTAF_NSCALARS, nullptr, B, P, st);
     launch_fill_scalars(hd->scalars, VISTAF_NSCALARS, hd->rel_count, hd->flipped, hd->amp_thr, hd->thr_used, hd->bg_med, hd->bad_count, B, st);
     launch_copy_out(hd->depth, orel, hd->status, d_height_mm, d_reliable, B, P, st);
@@ -663,6 +650,90 @@ int vistaf_ftp_predict_batch(vistaf_ftp_handle *hd, const void *d_frames, int fo
 #endif
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VISTAF_E_HIP, std::string("launch: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int vistaf_ftp_predict_batch(vistaf_ftp_handle *hd, const void *d_frames, int format, int B, float *d_height_mm, uint8_t *d_reliable,
+                             double *d_scalars, int32_t *d_status, void *stream)
+{
+    if (!hd || !d_frames) return fail(VISTAF_E_INVALID, "null argument");
+    if (!hd->have_ref) return fail(VISTAF_E_STATE, "set_reference has not been called");
+    if (B < 1 || B > hd->maxB) return fail(VISTAF_E_STATE, "batch exceeds max_batch");
+    if (format < 0 || format > 3) return fail(VISTAF_E_INVALID, "bad frame format");
+    if (!(hd->period > 1e-12)) return fail(VISTAF_E_STATE, "Invalid estimated_grating_period_px");
+    hipStream_t st = (hipStream_t)stream;
+    int h = hd->h, w = hd->w;
+    bool timed = hd->timing;
+    if (timed && !hd->ev_made) { for (int i = 0; i <= ST_COUNT; i++) hipEventCreate(&hd->ev[i]); hd->ev_made = true; }
+    HIPCHK(hipMemsetAsync(hd->status, 0, sizeof(int32_t) * B, st));
+
+    preprocess(hd, d_frames, format, B, st, timed);
+
+    // ---- demodulation, carrier locked to the reference (shape_ftp.py:1643-1653, :1681-1689)
+    if (timed) hipEventRecord(hd->ev[ST_DEMOD], st);
+    launch_dft_forward(hd->iw, hd->mu, hd->Ex, hd->Ey, 0, 0, hd->win, hd->tmpT, hd->patch, hd->pmax * hd->pmax, B, h, w, hd->ph, hd->pw, st);
+    launch_dft_inverse(hd->patch, hd->pmax * hd->pmax, hd->Gx, hd->Gy, 0, 0, hd->tmpT, hd->keep_planes ? hd->field : nullptr, hd->amp, hd->cref,
+                       hd->amp_ref, 0, hd->prod, hd->wrapped, B, h, w, hd->ph, hd->pw, st);
+    return post_demod(hd, B, d_height_mm, d_reliable, d_scalars, d_status, nullptr, st);
+}
+
+// Uncached pairs: every sample brings its own reference frame, as Code/height_to_force.py:384 runs shape_ftp.main per image (reference
+// demodulation with carrier search :1632-1639, then the deformed frame locked to it :1643-1653).  BASELINE configs[4] restated
+// (SURVEY.md 8d): B (reference, deformed) pairs, two demodulations per sample, no fusion of any kind exists upstream.
+int vistaf_ftp_predict_pairs(vistaf_ftp_handle *hd, const void *d_refs, const void *d_defs, int format, int B, float *d_height_mm,
+                             uint8_t *d_reliable, double *d_scalars, int32_t *d_status, void *stream)
+{
+    if (!hd || !d_refs || !d_defs) return fail(VISTAF_E_INVALID, "null argument");
+    if (B < 1 || B > hd->maxB) return fail(VISTAF_E_STATE, "batch exceeds max_batch");
+    if (format < 0 || format > 3) return fail(VISTAF_E_INVALID, "bad frame format");
+    hipStream_t st = (hipStream_t)stream;
+    const vistaf_ftp_config &c = hd->cfg;
+    int h = hd->h, w = hd->w, P = hd->P, pad = std::max(0, c.fft_pad_px), pm = hd->pmax;
+    bool timed = hd->timing;
+    if (timed && !hd->ev_made) { for (int i = 0; i <= ST_COUNT; i++) hipEventCreate(&hd->ev[i]); hd->ev_made = true; }
+    if (!hd->pairs_ready) {
+        int rc;
+        size_t mb = hd->maxB;
+        if ((rc = dalloc(hd, &hd->pgeom, mb)) || (rc = dalloc(hd, &hd->pEx, mb * w * pm)) || (rc = dalloc(hd, &hd->pGx, mb * w * pm)) ||
+            (rc = dalloc(hd, &hd->pEy, mb * h * pm)) || (rc = dalloc(hd, &hd->pGy, mb * h * pm)) || (rc = dalloc(hd, &hd->pcref, mb * P)) ||
+            (rc = dalloc(hd, &hd->pamp_ref, mb * P)) || (rc = dalloc(hd, &hd->win_full, (size_t)pm * pm)))
+            return rc;
+        std::vector<float> win = hann_patch(pm, pm);
+        HIPCHK(hipMemcpy(hd->win_full, win.data(), win.size() * sizeof(float), hipMemcpyHostToDevice));
+        hd->pairs_ready = true;
+    }
+    HIPCHK(hipMemsetAsync(hd->status, 0, sizeof(int32_t) * B, st));
+    const size_t sx = (size_t)w * pm, sy = (size_t)h * pm;
+    // ---- reference frames: preprocessing, carrier search, tables, demodulation
+    preprocess(hd, d_refs, format, B, st, false);
+    int rc = reference_search(hd, B, hd->pgeom, st);
+    if (rc) return rc;
+    launch_pair_status(hd->pgeom, pm, hd->status, B, st);
+    launch_build_tables(hd->pgeom, 1, hd->pEx, hd->pEy, hd->pGx, hd->pGy, sx, sy, B, h, w, pad, hd->Hf, hd->Wf, pm, st);
+    launch_dft_forward(hd->iw, hd->mu, hd->pEx, hd->pEy, sx, sy, hd->win_full, hd->tmpT, hd->patch, pm * pm, B, h, w, pm, pm, st);
+    launch_dft_inverse(hd->patch, pm * pm, hd->pGx, hd->pGy, sx, sy, hd->tmpT, hd->pcref, hd->pamp_ref, nullptr, nullptr, 0, nullptr, nullptr, B, h, w,
+                       pm, pm, st);
+    // ---- deformed frames, carrier locked to their own reference
+    preprocess(hd, d_defs, format, B, st, timed);
+    if (timed) hipEventRecord(hd->ev[ST_DEMOD], st);
+    launch_dft_forward(hd->iw, hd->mu, hd->pEx, hd->pEy, sx, sy, hd->win_full, hd->tmpT, hd->patch, pm * pm, B, h, w, pm, pm, st);
+    launch_dft_inverse(hd->patch, pm * pm, hd->pGx, hd->pGy, sx, sy, hd->tmpT, hd->keep_planes ? hd->field : nullptr, hd->amp, hd->pcref, hd->pamp_ref,
+                       (size_t)P, hd->prod, hd->wrapped, B, h, w, pm, pm, st);
+    return post_demod(hd, B, d_height_mm, d_reliable, d_scalars, d_status, hd->pgeom, st);
+}
+
+int vistaf_ftp_get_pair_info(vistaf_ftp_handle *hd, int batch, double *out /* [batch][VISTAF_NREFINFO] */, void *stream)
+{
+    if (!hd || !out) return fail(VISTAF_E_INVALID, "null argument");
+    if (!hd->pairs_ready || batch < 1 || batch > hd->maxB) return fail(VISTAF_E_STATE, "predict_pairs has not been called");
+    std::vector<CarrierGeom> g(batch);
+    HIPCHK(hipMemcpyAsync(g.data(), hd->pgeom, sizeof(CarrierGeom) * batch, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    for (int b = 0; b < batch; b++) {
+        double *o = out + (size_t)b * VISTAF_NREFINFO;
+        o[0] = g[b].peak_x; o[1] = g[b].peak_y; o[2] = g[b].kx; o[3] = g[b].ky; o[4] = hd->Hf; o[5] = hd->Wf; o[6] = g[b].period;
+        o[7] = g[b].period > 1e-12 ? hd->cfg.grating_pitch_mm / g[b].period : 0.0;
+    }
     return 0;
 }
 

@@ -329,7 +329,9 @@ __global__ __launch_bounds__(1024) void k_tail(const float *__restrict__ height_
     double vol = block_sum<double>(use_neg ? voln : volp, sd);
     double cntd = block_sum<double>((double)(use_neg ? cntn : cntp), sd);
     unsigned long long mx = block_max_u64(use_neg ? mxn : mxp, s64);
-    double area_px = pp.mm_per_px * pp.mm_per_px;
+    double period_px = pp.period_px, mm_per_px = pp.mm_per_px;
+    if (pp.pair_geom) { period_px = pp.pair_geom[b].period; mm_per_px = period_px > 1e-12 ? pp.grating_pitch_mm / period_px : 0.0; }
+    double area_px = mm_per_px * mm_per_px;
     double volume_cm3 = cntd > 0 ? (double)(float)vol * area_px / 1000.0 : 0.0;
     double area_mm2 = cntd * area_px;
     double maxd = cntd > 0 ? (double)__uint_as_float((unsigned int)(mx >> 32)) : 0.0;
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(1024) void k_tail(const float *__restrict__ height_
         S[0] = volume_cm3; S[1] = area_mm2; S[2] = maxd;
         S[3] = curve_eval(pp.force_curve, volume_cm3);
         S[4] = am ? (double)(0xffffffffu - (unsigned int)(am & 0xffffffffu)) : -1.0;
-        S[5] = pp.period_px; S[6] = pp.mm_per_px;
+        S[5] = period_px; S[6] = mm_per_px;
         if (unitless && an != ~0ull) { S[7] = (double)key2f((unsigned int)(an >> 32)); S[8] = (double)(unsigned int)(an & 0xffffffffu); }
         else { S[7] = (double)nanf32(); S[8] = -1.0; }
     }
@@ -395,7 +397,7 @@ __global__ void k_copy_out(const float *__restrict__ depth, const uint8_t *__res
     size_t b = blockIdx.y;
     if (p >= P) return;
     size_t i = b * (size_t)P + p;
-    bool empty = status[b] == 1;
+    bool empty = status[b] == 1 || status[b] == 3;     // empty reliable mask (upstream returns None) / no carrier (pair mode)
     if (out_h) out_h[i] = empty ? nanf32() : depth[i];
     if (out_r) out_r[i] = empty ? 0 : reliable[i];
 }

@@ -69,6 +69,8 @@ void launch_carrier_choose(const double *peaks, int npk, const double *mag, int 
                            hipStream_t st);
 void launch_build_tables(const CarrierGeom *geom, int geom_stride, double2 *Ex, double2 *Ey, double2 *Gx, double2 *Gy, size_t stride_x,
                          size_t stride_y, int B, int h, int w, int pad, int Hf, int Wf, int pmax, hipStream_t st);
+// pair mode: frames without a usable carrier (or whose patch is clipped by the spectrum border) get status VISTAF_FRAME_NO_CARRIER
+void launch_pair_status(const CarrierGeom *geom, int pmax, int32_t *status, int B, hipStream_t st);
 void launch_build_full_tables(double2 *Exf, double2 *Eyf, int h, int w, int pad, int Hf, int Wf, hipStream_t st);
 
 // ---- k_cc_dist.hip ----------------------------------------------------------------------------
@@ -122,6 +124,8 @@ void launch_hole_merge(float *hmap, const uint8_t *reliable, const uint8_t *cand
 struct PostParams {
     double mm_per_px, depth_eps_mm, period_px;
     Curve force_curve;
+    const CarrierGeom *pair_geom = nullptr;     // pair mode: per-frame period (mm_per_px = grating_pitch_mm / period, force_sensor.py:173-187)
+    double grating_pitch_mm = 0.0;
 };
 void launch_contact_mask(const float *res, const uint8_t *reliable, const float *thr3, const int *rel_count, int *contact_count,
                          float min_frac, float max_frac, uint8_t *contact, float *thr_used, int B, int P, hipStream_t st);

@@ -127,7 +127,10 @@ class FtpSensor:
 
     def __init__(self, reference, roi_circle: Optional[Tuple[int, int, int]] = None, config: Optional[FtpConfig] = None,
                  height_model: Optional[Dict[str, Any]] = None, use_negated_height: bool = True,
-                 force_model: Optional[Dict[str, Any]] = None, max_batch: int = 256, device="cuda:0"):
+                 force_model: Optional[Dict[str, Any]] = None, max_batch: int = 256, device="cuda:0",
+                 frame_shape: Optional[Tuple[int, int]] = None):
+        """reference: the session's reference frame, or None for a session that only runs `predict_pairs` (every sample then brings its
+        own reference frame; `frame_shape` = (h, w) is needed instead)."""
         self._lib = _lib.load()
         self._h = ctypes.c_void_p()
         if not torch.cuda.is_available():
@@ -136,10 +139,16 @@ class FtpSensor:
         self.config = config or FtpConfig.as_shipped()
         if height_model is None or force_model is None:
             raise KeyError("height_model and force_model (the 'best_model' blocks of the calibration JSONs) are required")
-        ref = self._as_frames(reference)
-        if ref.shape[0] != 1:
-            raise ValueError("reference must be a single frame")
-        self.h, self.w = int(ref.shape[1]), int(ref.shape[2])
+        if reference is None:
+            if frame_shape is None:
+                raise ValueError("a session without a reference frame needs frame_shape=(h, w)")
+            ref = None
+            self.h, self.w = int(frame_shape[0]), int(frame_shape[1])
+        else:
+            ref = self._as_frames(reference)
+            if ref.shape[0] != 1:
+                raise ValueError("reference must be a single frame")
+            self.h, self.w = int(ref.shape[1]), int(ref.shape[2])
         if roi_circle is None:
             roi_circle = (self.w // 2, self.h // 2, min(self.h, self.w) // 2 - 1)
         self.roi_circle = tuple(int(v) for v in roi_circle)
@@ -151,13 +160,20 @@ class FtpSensor:
             _lib.check(self._lib.vistaf_ftp_create(ctypes.byref(cc), self.h, self.w, *self.roi_circle, self.max_batch,
                                                    ctypes.byref(hc), int(bool(use_negated_height)), ctypes.byref(fc),
                                                    ctypes.byref(self._h)))
-            fmt = self._format_of(ref)
-            _lib.check(self._lib.vistaf_ftp_set_reference(self._h, ref.data_ptr(), fmt, _stream_ptr(self.device)))
-        info = (ctypes.c_double * _lib.NREFINFO)()
-        _lib.check(self._lib.vistaf_ftp_get_reference_info(self._h, info))
-        self.reference_info = {
-            "peak_refined": (info[0], info[1]), "k": (info[2], info[3]), "fft_shape": (int(info[4]), int(info[5])),
-            "estimated_grating_period_px": info[6], "mm_per_px": info[7],
+            if ref is not None:
+                fmt = self._format_of(ref)
+                _lib.check(self._lib.vistaf_ftp_set_reference(self._h, ref.data_ptr(), fmt, _stream_ptr(self.device)))
+        self.reference_info = None
+        if ref is not None:
+            info = (ctypes.c_double * _lib.NREFINFO)()
+            _lib.check(self._lib.vistaf_ftp_get_reference_info(self._h, info))
+            self.reference_info = self._info_dict(info, 0)
+
+    @staticmethod
+    def _info_dict(info, o):
+        return {
+            "peak_refined": (info[o + 0], info[o + 1]), "k": (info[o + 2], info[o + 3]), "fft_shape": (int(info[o + 4]), int(info[o + 5])),
+            "estimated_grating_period_px": info[o + 6], "mm_per_px": info[o + 7],
         }
 
     # -- helpers ---------------------------------------------------------------------------------
@@ -213,6 +229,39 @@ class FtpSensor:
                 out["scalars"].data_ptr(), out["status"].data_ptr(), _stream_ptr(self.device)))
         self._last_out = out
         return out
+
+    def predict_pairs(self, references, frames, out: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+        """Uncached pairs: sample b = (references[b], frames[b]); every sample's reference frame is demodulated with its own carrier
+        search, as Code/height_to_force.py:384 does by calling shape_ftp.main once per image.  Same outputs as predict_batch; status 3
+        marks a sample whose reference spectrum holds no usable carrier."""
+        r, t = self._as_frames(references), self._as_frames(frames)
+        if r.shape != t.shape or r.dtype != t.dtype:
+            raise RuntimeError("Reference and deformed images have different sizes.")   # shape_ftp.py:1477-1478
+        b = int(t.shape[0])
+        if t.shape[1] != self.h or t.shape[2] != self.w:
+            raise RuntimeError("Reference and deformed images have different sizes.")
+        if b > self.max_batch:
+            raise RuntimeError(f"batch {b} exceeds max_batch {self.max_batch}")
+        if out is None:
+            out = {
+                "height_map_mm": torch.empty((b, self.h, self.w), dtype=torch.float32, device=self.device),
+                "output_reliable": torch.empty((b, self.h, self.w), dtype=torch.uint8, device=self.device),
+                "scalars": torch.empty((b, _lib.NSCALARS), dtype=torch.float64, device=self.device),
+                "status": torch.empty((b,), dtype=torch.int32, device=self.device),
+            }
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.vistaf_ftp_predict_pairs(
+                self._h, r.data_ptr(), t.data_ptr(), self._format_of(t), b, out["height_map_mm"].data_ptr(), out["output_reliable"].data_ptr(),
+                out["scalars"].data_ptr(), out["status"].data_ptr(), _stream_ptr(self.device)))
+        self._last_out = out
+        return out
+
+    def pair_info(self, batch: int):
+        """reference_info of every sample of the last predict_pairs"""
+        info = (ctypes.c_double * (_lib.NREFINFO * batch))()
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.vistaf_ftp_get_pair_info(self._h, batch, info, _stream_ptr(self.device)))
+        return [self._info_dict(info, b * _lib.NREFINFO) for b in range(batch)]
 
     def intermediate(self, name: str, batch: int, dtype=torch.float32) -> torch.Tensor:
         """Copy of a named intermediate plane of the last predict_batch (parity tests)."""
