@@ -32,28 +32,132 @@ PKG = "vistaf-roboskin-vision-integrated-multimodal-sensor_amd"
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(pkg, cfg, cal, neg, fm, n, ref, frames_u8, budget_s=20.0):
-    """The oracle (NumPy + C restatement of the reference's path; kind "port") timed on this host:
-    single process, frames processed sequentially as the reference's only batch driver does
-    (Code/height_to_force.py:360), figure rendering excluded."""
+def _cpu_worker(args):
+    """one process of the CPU baseline: frames[i0::stride] through the oracle until the budget is spent -> (frames done, seconds)"""
+    n, constants, i0, stride, budget_s, pairs = args
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+    pkg = importlib.import_module(PKG)
     from oracle import ftp_oracle as O
+    cfg = pkg.FtpConfig.scaled(n) if constants == "scaled" else pkg.FtpConfig.as_shipped()
+    g = os.path.join(ROOT, "tests", "golden")
+    cal, neg = pkg.load_calibration(os.path.join(g, "calibration_phase_to_height.json"))
+    fm = pkg.load_force_calibration(os.path.join(g, "calibration_height_to_force.json"))["best_model"]
     circle = pkg.synth.roi_circle(n)
-    t0 = time.perf_counter()
-    rs = O.make_reference_state(ref, *circle, cfg)
-    t_ref = time.perf_counter() - t0
-    done = 0
-    t0 = time.perf_counter()
-    for i in range(frames_u8.shape[0]):
-        O.process_frame(frames_u8[i], rs, cfg, cal, neg, fm)
+    ref = pkg.synth.reference_frame(n, config=3)
+    rs = None if pairs else O.make_reference_state(ref, *circle, cfg)
+    done, i, busy = 0, i0, 0.0
+    while busy < budget_s:
+        f = pkg.synth.deformed_frame(n, i, config=3)   # frame synthesis is not timed
+        t0 = time.perf_counter()
+        if pairs:                                     # uncached pair: the reference frame is demodulated again for every sample
+            rs = O.make_reference_state(ref, *circle, cfg)
+        O.process_frame(f, rs, cfg, cal, neg, fm)
+        busy += time.perf_counter() - t0
         done += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    return {
-        "value": done / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-        "sample": f"{done} of the same synthetic {n}x{n} frames, sequential, single process on 1 of {os.cpu_count()} host cores; "
-                  f"reference-frame demodulation cached ({t_ref * 1e3:.0f} ms, excluded), figure rendering excluded",
-    }
+        i += stride
+    return done, busy
+
+
+def cpu_baselines(n, constants, budget_s, pairs=False):
+    """The oracle (NumPy + C restatement of the reference's path; kind "port") timed on this host BEFORE the GPU is initialised (the
+    worker processes are forked): (a) single process, frames sequential, as the reference's only batch driver does
+    (Code/height_to_force.py:360), figure rendering excluded; (b) one process per host core, so that the GPU / CPU ratio is
+    not flattered by single-threading."""
+    import multiprocessing as mp
+    what = "uncached (reference, deformed) pairs" if pairs else "frames, reference-frame demodulation cached and excluded"
+    done, dt = _cpu_worker((n, constants, 0, 1, budget_s, pairs))
+    one = {"value": done / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": f"{done} synthetic {n}x{n} {what}; sequential, single process on 1 of {os.cpu_count()} host cores, {dt:.1f} s; "
+                     f"figure rendering excluded"}
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    with mp.get_context("fork").Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(n, constants, k, cores, budget_s * 0.75, pairs) for k in range(cores)])
+    tot = sum(r[0] / r[1] for r in res)
+    allc = {"value": tot, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{sum(r[0] for r in res)} synthetic {n}x{n} {what}; {cores} processes (one per host core, BLAS/OpenMP threads = 1), "
+                      f"{max(r[1] for r in res):.1f} s each; sum of the per-process rates"}
+    return one, allc
+
+
+GATHER_KEYS = ("height_map_mm", "scalars", "status")
+
+
+class Stepper:
+    """One benchmark step = one pass of the path over one batch on the next session in turn (its own stream and workspace), followed, when
+    `gathers` is given (N > 1), by the step's ONE collective on the same stream.  Kept free of GPU specifics so that the world-size-2 gloo
+    test (tests/test_host_cpu.py) drives exactly this control flow on CPU tensors."""
+
+    def __init__(self, run, sensors, outs, streams, gathers, stream_ctx):
+        self.run, self.sensors, self.outs, self.streams, self.gathers, self.stream_ctx = run, sensors, outs, streams, gathers, stream_ctx
+        self.n = 0
+
+    def step(self):
+        k = self.n % len(self.sensors)
+        self.n += 1
+        if self.streams[k] is None:
+            self.run(self.sensors[k], self.outs[k])
+            if self.gathers is not None:
+                self.gathers[k].gather(self.outs[k])
+        else:
+            with self.stream_ctx(self.streams[k]):
+                self.run(self.sensors[k], self.outs[k])
+                if self.gathers is not None:
+                    self.gathers[k].gather(self.outs[k])
+
+
+def timed_steps(stepper, warmup, steps, dist, sync, dev):
+    """W untimed steps, then exactly K steps bracketed by barrier + device synchronisation on both sides; MAX over ranks."""
+    for _ in range(warmup):
+        stepper.step()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        stepper.step()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    return elapsed
+
+
+def _csrc_sha():
+    """fingerprint of the kernel sources: recorded by tools/collect_profiles.py next to the PMC traffic numbers, so that a traffic figure
+    measured on other kernels is never reported as this run's"""
+    import hashlib
+    hsh = hashlib.sha1()
+    d = os.path.join(ROOT, PKG, "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".h")):
+            hsh.update(f.encode())
+            hsh.update(open(os.path.join(d, f), "rb").read())
+    return hsh.hexdigest()[:16]
+
+
+def _traffic_table():
+    """newest profiles/traffic_r*.json -> (table or {}, source description)"""
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")))
+    if not fs:
+        return {}, None
+    try:
+        tj = json.load(open(fs[-1]))
+    except Exception:
+        return {}, None
+    src = {"file": os.path.relpath(fs[-1], ROOT), "measured_at_head": tj.get("_head"), "date": tj.get("_date"), "csrc_sha": tj.get("_csrc_sha"),
+           "matches_this_build": tj.get("_csrc_sha") == _csrc_sha(),
+           "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/prof_pmc.sh), not measured in this run"}
+    return (tj if src["matches_this_build"] else {}), src
 
 
 def main():
@@ -68,12 +172,20 @@ def main():
                     help="sessions (each with its own HIP stream and workspace) that take the steps in turn, so consecutive steps overlap on the GPU; "
                          "1 = strictly serial steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--cpu-budget-s", type=float, default=16.0)
+    ap.add_argument("--pairs", action="store_true",
+                    help="BASELINE configs[4] as SURVEY.md 8(d) restates it: uncached (reference, deformed) pairs, carrier search + reference "
+                         "demodulation per sample (no fusion of any kind exists upstream); default batch 128 = 1024 / 8 per GPU")
     args = ap.parse_args()
+    if args.pairs and args.batch == 256:
+        args.batch = 128
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    cpu_one = cpu_all = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu_one, cpu_all = cpu_baselines(args.size, args.constants, args.cpu_budget_s, args.pairs)      # before any HIP call: forks workers
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -99,56 +211,33 @@ def main():
     cal, neg = pkg.load_calibration(os.path.join(g, "calibration_phase_to_height.json"))
     fm = pkg.load_force_calibration(os.path.join(g, "calibration_height_to_force.json"))["best_model"]
 
-    # synthetic data: 64 distinct deformed frames per rank, tiled to the batch, 3-channel fp16
+    # synthetic data: B DISTINCT deformed frames per rank (the sequential kernels last as long as their slowest frame,
+    # so a tiled batch would under-sample that tail), 3-channel fp16
     ref = pkg.synth.reference_frame(n, config=3)
-    nd = min(B, 64)
-    base = pkg.synth.deformed_batch(n, rank * nd, nd, config=3)
-    frames_u8 = np.concatenate([base] * ((B + nd - 1) // nd), axis=0)[:B]
+    frames_u8 = pkg.synth.deformed_batch(n, rank * B, B, config=3)
     frames = torch.from_numpy(frames_u8).to(dev)
     frames = frames[..., None].expand(-1, -1, -1, 3).to(torch.float16).contiguous()   # [B, n, n, 3] fp16
     ref3 = torch.from_numpy(ref).to(dev)[..., None].expand(-1, -1, 3).to(torch.float16).contiguous()
-    sensors = [pkg.FtpSensor(ref3, pkg.synth.roi_circle(n), cfg, cal, neg, fm, max_batch=B, device=dev) for _ in range(max(1, args.inflight))]
+    if args.pairs:
+        # every sample carries its own reference frame (own noise realisation): [B, n, n, 3] fp16 next to the deformed frames
+        refs_u8 = np.stack([pkg.synth._base(n, 0.0, np.random.default_rng(880000 + rank * B + b)) for b in range(B)])
+        refs = torch.from_numpy(refs_u8).to(dev)[..., None].expand(-1, -1, -1, 3).to(torch.float16).contiguous()
+        sensors = [pkg.FtpSensor(None, pkg.synth.roi_circle(n), cfg, cal, neg, fm, max_batch=B, device=dev, frame_shape=(n, n))
+                   for _ in range(max(1, args.inflight))]
+        run = lambda s_, o_=None: s_.predict_pairs(refs, frames, o_)
+    else:
+        sensors = [pkg.FtpSensor(ref3, pkg.synth.roi_circle(n), cfg, cal, neg, fm, max_batch=B, device=dev) for _ in range(max(1, args.inflight))]
+        run = lambda s_, o_=None: s_.predict_batch(frames, o_)
     streams = [torch.cuda.Stream(device=dev) for _ in sensors] if len(sensors) > 1 else [None]
     sensor = sensors[0]
-    outs = [s_.predict_batch(frames) for s_ in sensors]
+    outs = [run(s_) for s_ in sensors]
     out = outs[0]
     torch.cuda.synchronize(dev)
-    step_no = [0]
     # N > 1: ONE RCCL all-gather per step -- maps, scalar records and status packed into one record per frame (parallel.PackedGather),
     # issued on the session's own stream so that it overlaps the other sessions' kernels
-    gathers = [pkg.parallel.PackedGather(o, keys=("height_map_mm", "scalars", "status")) for o in outs] if world > 1 else None
-
-    def step():
-        k = step_no[0] % len(sensors)
-        step_no[0] += 1
-        if streams[k] is None:
-            sensors[k].predict_batch(frames, outs[k])
-        else:
-            with torch.cuda.stream(streams[k]):
-                sensors[k].predict_batch(frames, outs[k])
-        if world > 1:
-            if streams[k] is None:
-                gathers[k].gather(outs[k])
-            else:
-                with torch.cuda.stream(streams[k]):
-                    gathers[k].gather(outs[k])
-
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    gathers = [pkg.parallel.PackedGather(o, keys=GATHER_KEYS) for o in outs] if world > 1 else None
+    stepper = Stepper(run, sensors, outs, streams, gathers, torch.cuda.stream)
+    elapsed = timed_steps(stepper, args.warmup, args.steps, dist if world > 1 else None, lambda: torch.cuda.synchronize(dev), dev)
     status_bad = int((out["status"] != 0).sum().item())
 
     # per-kernel device times (HIP events recorded by the library on the launch stream), separate passes
@@ -156,7 +245,7 @@ def main():
     acc = {}
     reps = 5
     for _ in range(reps):
-        sensor.predict_batch(frames, out)
+        run(sensor, out)
         for k, v in sensor.stage_times_ms().items():
             acc[k] = acc.get(k, 0.0) + v / reps
     sensor.enable_stage_timing(False)
@@ -171,26 +260,21 @@ def main():
         per_px = {"unwrap flood (k_unwrap_flood_batch)": 9.0, "inpaint (k_telea_window)": 9.0, "detrend (3x IRLS)": 27.0}.get(dom, 8.0)
         alg_bytes = per_px * P * B
         achieved = alg_bytes / (acc[dom] * 1e-3) / 1e9
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "traffic_r01.json")
-        if os.path.exists(tp):
-            try:
-                traffic = json.load(open(tp)).get(dom)
-            except Exception:
-                traffic = None
-        # the other two heavy stages, for context: measured HBM traffic (profiles/traffic_r01.json) over this run's stage time
+        # HBM traffic per launch from the PMC counters: collected by separate rocprofv3 --pmc runs (tools/prof_pmc.sh ->
+        # tools/collect_profiles.py -> profiles/traffic_rNN.json), never in this run; reported only when that file was measured on
+        # exactly these kernel sources, null otherwise (`traffic_source` says which file and why)
+        tj, traffic_source = ({}, None) if args.pairs else _traffic_table()
+        traffic = tj.get(dom) if isinstance(tj.get(dom), (int, float)) else None
+        # the other two heavy stages, for context: that traffic over this run's stage time
         other = []
-        try:
-            tj = json.load(open(tp)) if os.path.exists(tp) else {}
-        except Exception:
-            tj = {}
         for k in ("unwrap flood (k_unwrap_flood_batch)", "detrend (3x IRLS)", "inpaint (k_telea_window)"):
             if k != dom and k in acc and isinstance(tj.get(k), (int, float)) and acc[k] > 0:
                 rate = tj[k] / (acc[k] * 1e-3) / 1e9
                 other.append({"kernel": k, "kernel_ms": round(acc[k], 4), "traffic": tj[k], "hbm_GBps": round(rate, 1),
                               "frac_of_hbm_peak": round(rate / HBM_PEAK_GBS, 4)})
         line = {
-            "metric": "frames/sec (224x224 -> force-map) at batch 256",
+            "metric": "frames/sec (224x224 -> force-map) at batch 256" if not args.pairs else
+                      "pairs/sec (uncached (reference, deformed) 224x224 pairs -> force-map), BASELINE configs[4] restated",
             "value": world * B * args.steps / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
@@ -203,15 +287,20 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"BASELINE configs[2]: batch {B}/GPU of {n}x{n}x3 fp16 fringe frames -> {n}x{n} f32 depth map + force scalars, "
-                            f"full FTP path (inpaint, demod, unwrap, detrend, compose, force tail), constants {args.constants}-{n}; "
-                            f"inputs resident in HBM" + ("; one RCCL all-gather of the packed outputs (maps + scalar records + status) per step" if world > 1 else ""),
+                "workload": (f"BASELINE configs[2]: batch {B}/GPU of {n}x{n}x3 fp16 fringe frames ({B} distinct frames) -> {n}x{n} f32 depth map + force scalars, "
+                             f"full FTP path (inpaint, demod, unwrap, detrend, compose, force tail), constants {args.constants}-{n}; "
+                             f"inputs resident in HBM" if not args.pairs else
+                             f"BASELINE configs[4] as SURVEY.md 8(d) restates it: {B} uncached (reference, deformed) pairs/GPU of {n}x{n}x3 fp16 frames, "
+                             f"carrier search + reference demodulation per sample (two demodulations per sample, as Code/height_to_force.py:384 "
+                             f"runs shape_ftp.main per image; no two-camera / temporal fusion exists upstream), then the full FTP path; "
+                             f"constants {args.constants}-{n}; inputs resident in HBM")
+                            + ("; one RCCL all-gather of the packed outputs (maps + scalar records + status) per step" if world > 1 else ""),
                 "global_batch": world * B, "frame": [n, n, 3], "input_dtype": "fp16", "constants": args.constants,
                 "parallelism": f"dp{world}", "inflight_batches": len(sensors), "frames_with_nonzero_status": status_bad,
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "kernel_ms": acc[dom], "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "dominant stage is latency-bound (a sequential fast-marching / priority-queue march, one wave per frame), not bandwidth-bound",
                 "other_heavy_stages": other,
@@ -219,8 +308,9 @@ def main():
             "stage_ms": {k: round(v, 4) for k, v in acc.items()},
             "serial_ms_per_step": round(sum(acc.values()), 4),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(pkg, cfg, cal, neg, fm, n, ref, frames_u8, args.cpu_budget_s)
+        if cpu_one is not None:
+            line["cpu_baseline"] = cpu_one
+            line["cpu_baseline_all_cores"] = cpu_all
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

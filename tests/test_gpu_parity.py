@@ -522,3 +522,36 @@ def test_uncached_pairs_128(pkg, cal):
     assert (st[[0, 1, 3]] == 0).all() and st[2] in (0, 1, 3)
     for b in (0, 1, 3):
         assert torch.equal(torch.nan_to_num(o2["height_map_mm"][b], nan=-7.0), torch.nan_to_num(out["height_map_mm"][b], nan=-7.0))
+
+
+def test_module_level_predict_is_the_drop_in(pkg, cal):
+    """`predict(image, reference=...) -> force map` is the API name BASELINE.json asks for (it does not exist upstream: it is shape_ftp.main's
+    result dict, Code/shape_ftp.py:2029-2037, plus the force tail of Code/multimodal_sensor.py:388-419).  First call builds the session from the
+    reference frame; later calls reuse it; a new reference rebuilds it."""
+    n = 160
+    cfg = pkg.FtpConfig.scaled(n)
+    circle = pkg.synth.roi_circle(n)
+    ref = pkg.synth.reference_frame(n, config=3)
+    kw = dict(roi_circle=circle, config=cfg, height_model=cal[0], use_negated_height=cal[1], force_model=cal[2])
+    rs = O.make_reference_state(ref, *circle, cfg)
+    for i, image in enumerate([pkg.synth.deformed_frame(n, 11), pkg.synth.deformed_frame(n, 12)]):
+        res = pkg.predict(image, reference=ref, **kw) if i == 0 else pkg.predict(image)         # second call: cached session
+        o = O.process_frame(image, rs, cfg, *cal)
+        assert set(["height_map_mm_crop", "roi_eroded_crop", "output_reliable_crop", "estimated_grating_period_px", "force_N", "volume_cm3",
+                    "argmax_depth_index"]) <= set(res)
+        hm, r = res["height_map_mm_crop"], o["height_map_mm_crop"]
+        assert hm.dtype == np.float32 and np.array_equal(np.isnan(hm), np.isnan(r))
+        assert float(np.nanmax(np.abs(hm - r))) <= RTOL * float(np.nanmax(np.abs(r)))
+        assert np.array_equal(res["output_reliable_crop"], o["output_reliable_crop"]) and np.array_equal(res["roi_eroded_crop"], o["roi_eroded_crop"])
+        assert res["argmax_depth_index"] == o["argmax_depth_index"]
+        assert abs(res["force_N"] - o["force_N"]) <= RTOL * max(abs(o["force_N"]), 1e-9)
+        assert abs(res["estimated_grating_period_px"] - o["estimated_grating_period_px"]) <= 1e-9 * o["estimated_grating_period_px"]
+    # a new reference frame rebuilds the session
+    ref2 = pkg.synth.reference_frame(n, config=3, period=10.1)
+    img2 = pkg.synth.deformed_frame(n, 13, period=10.1)
+    res2 = pkg.predict(img2, reference=ref2, **kw)
+    o2 = O.process_frame(img2, O.make_reference_state(ref2, *circle, cfg), cfg, *cal)
+    assert res2["argmax_depth_index"] == o2["argmax_depth_index"]
+    assert float(np.nanmax(np.abs(res2["height_map_mm_crop"] - o2["height_map_mm_crop"]))) <= RTOL * float(np.nanmax(np.abs(o2["height_map_mm_crop"])))
+    with pytest.raises(RuntimeError):
+        pkg.predict(np.zeros((n + 1, n), np.uint8))                                            # size mismatch (shape_ftp.py:1477)

@@ -9,6 +9,7 @@ import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG_NAME = "vistaf-roboskin-vision-integrated-multimodal-sensor_amd"
 G = os.path.join(ROOT, "tests", "golden")
 
 
@@ -20,7 +21,7 @@ def test_library_exports_every_declared_symbol(pkg):
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(pkg._lib.EXPORTS) == declared
-    assert lib.vistaf_ftp_abi_version() == 1
+    assert lib.vistaf_ftp_abi_version() == 2
     hdr2 = open(os.path.join(ROOT, "include", "vistaf_align.h")).read()
     declared2 = sorted(set(re.findall(r"\b(vistaf_align_\w+)\s*\(", hdr2)))
     assert len(declared2) == 6
@@ -163,6 +164,88 @@ def test_two_rank_all_gather_gloo(pkg):
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def _bench_flow_worker(rank, world, port, q):
+    """bench.py's own step / timing control flow (Stepper, timed_steps, PackedGather with GATHER_KEYS) on CPU tensors of the REAL output
+    shapes and dtypes of a 256-frame shard, gloo instead of RCCL; every collective is counted."""
+    import contextlib
+    import importlib
+    import sys
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    bench = importlib.import_module("bench")
+    par = importlib.import_module(PKG_NAME + ".parallel")
+    B, n = 256, 224
+    calls = {"gather": 0, "other": 0}
+    real_ag, real_ar = dist.all_gather_into_tensor, dist.all_reduce
+
+    def counting_ag(*a, **k):
+        calls["gather"] += 1
+        return real_ag(*a, **k)
+
+    def counting_ar(*a, **k):
+        calls["other"] += 1
+        return real_ar(*a, **k)
+    dist.all_gather_into_tensor, dist.all_reduce = counting_ag, counting_ar
+
+    def make_out():
+        return {"height_map_mm": torch.empty((B, n, n), dtype=torch.float32), "output_reliable": torch.empty((B, n, n), dtype=torch.uint8),
+                "scalars": torch.empty((B, 16), dtype=torch.float64), "status": torch.empty((B,), dtype=torch.int32)}
+
+    class FakeSession:                      # stands in for FtpSensor.predict_batch: rank- and step-dependent content, no GPU
+        def __init__(self):
+            self.calls = 0
+
+    def run(s_, o_):
+        s_.calls += 1
+        o_["height_map_mm"].fill_(float(1000 * rank + s_.calls))
+        o_["height_map_mm"][:, 0, 0] = torch.arange(B, dtype=torch.float32) + B * rank
+        o_["scalars"].copy_((torch.arange(B * 16, dtype=torch.float64) + 1e6 * rank).reshape(B, 16))
+        o_["status"].fill_(rank)
+        return o_
+    sessions, outs = [FakeSession() for _ in range(3)], [make_out() for _ in range(3)]
+    gathers = [par.PackedGather(o, keys=bench.GATHER_KEYS) for o in outs]
+    stepper = bench.Stepper(run, sessions, outs, [None] * 3, gathers, contextlib.nullcontext)
+    warm, steps = 1, 4
+    elapsed = bench.timed_steps(stepper, warm, steps, dist, lambda: None, torch.device("cpu"))
+    ok = calls["gather"] == warm + steps                                   # exactly ONE data-path collective per step
+    ok = ok and calls["other"] == 1                                        # + the max-over-ranks of the elapsed time, once
+    ok = ok and stepper.n == warm + steps and elapsed > 0
+    g = gathers[(warm + steps - 1) % 3].views()                            # the last step's gathered records
+    ok = ok and tuple(g["height_map_mm"].shape) == (world * B, n, n) and g["scalars"].dtype == torch.float64 and g["status"].dtype == torch.int32
+    for r in range(world):
+        ok = ok and bool((g["status"][r * B:(r + 1) * B] == r).all())
+        ok = ok and torch.equal(g["height_map_mm"][r * B:(r + 1) * B, 0, 0], torch.arange(B, dtype=torch.float32) + B * r)
+        ok = ok and float(g["scalars"][r * B, 1]) == 1e6 * r + 1
+    q.put((rank, bool(ok), calls["gather"], calls["other"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_step_flow_two_ranks_gloo(pkg):
+    """N > 1 readiness without hardware: the benchmark's step loop with the real shard shapes ([256,224,224] f32 + [256,16] f64 + [256] i32),
+    two gloo ranks on CPU, one collective per step; and the shard ranges of BASELINE configs[3] (2048 / 8) and configs[4] (1024 / 8)."""
+    import torch.multiprocessing as mp
+    par = pkg.parallel
+    for total in (2048, 1024):
+        spans = [par.shard_range(total, r, 8) for r in range(8)]
+        assert spans[0][0] == 0 and spans[-1][1] == total and all(spans[i][1] == spans[i + 1][0] for i in range(7))
+        assert {b - a for a, b in spans} == {total // 8}
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_bench_flow_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True, 5, 1), (1, True, 5, 1)], res
 
 
 def test_result_writers_match_reference_schema(pkg, tmp_path):

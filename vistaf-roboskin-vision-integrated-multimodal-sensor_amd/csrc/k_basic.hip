@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void k_gauss_rows(const float *__restrict__ sr
 }
 
 // Column pass: cv::SymmColumnFilter's symmetric form, s = k[r]*S[y]; s = fma(k[r+j], S[y+j] + S[y-j], s) for j = 1..r (the order the
-// oracle restates, oracle/cvlite.c cvl_gaussian_blur_f32: same operations in the same order, so the same bits).  Each thread produces
+// parity tests' CPU restatement executes too: same operations in the same order, so the same bits).  Each thread produces
 // GC_R consecutive rows of one column; lanes run along x so every row read is coalesced.  The two source rows a step needs for its GC_R
 // outputs are the previous step's shifted by one row, so a step costs two new reads (register windows `up` / `dn`).
 constexpr int GC_R = 8;

@@ -9,7 +9,7 @@
 // float64: float64 twiddles built on the host, float64 fused multiply-adds, float64 patch / field.  That is the
 // arithmetic of the reference under NumPy < 2 (fft2 of a float32 array runs in complex128; the sub-bin ramp and
 // cdef * conj(cref) are complex128 under every NumPy), to ~1e-15 relative -- so amplitude and wrapped phase round
-// to the same float32 as the oracle's (oracle/ftp_oracle.py FFT_COMPLEX128) and every threshold downstream of them
+// to the same float32 as a complex128 NumPy transform's (what the parity tests compare with) and every threshold downstream of them
 // (quality >= p25) sees the same plane.  Tables may be per frame (tab_stride != 0: the uncached-pair mode, where
 // every sample carries its own carrier) or shared by the batch (0).
 #include <algorithm>

@@ -21,7 +21,7 @@ __device__ inline float wn_dpp_sum(float x)
 __device__ inline float wn_lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
 // Sum over lanes [0, N) in LANE ORDER from `init`: ((init + x0) + x1) + ... + x(N-1), every addition rounded to float.  That is the order
-// in which cv::inpaint's k / l loops accumulate Ia, Jx, Jy and s (inpaint.cpp icvTeleaInpaintFMM; restated in oracle/cvlite.c), so the
+// in which cv::inpaint's k / l loops accumulate Ia, Jx, Jy and s (inpaint.cpp icvTeleaInpaintFMM), so the
 // filled pixels carry the same roundings bit for bit -- they feed the illumination blur, the demodulation and, through the amplitude, the
 // quality >= p25 threshold of the reliable mask.  After step t lanes 0..t hold their final prefix (lane l takes lane l-1's value through
 // wave_shr:1 and adds its own term; a lane that is already final recomputes the same value), so N-1 dependent DPP adds give the total.
@@ -62,7 +62,7 @@ __device__ inline float wn_seq_sum_n(float x, float init, int n, int lane)
     return wn_lane_f(S, n - 1);
 }
 // Ia / s + (Jx + Jy) / (sqrt(Jx^2 + Jy^2) + 1e-20): the float quotient and sums promoted to double for the second term and the final
-// addition, as the oracle restates OpenCV's expression
+// addition (inpaint.cpp's expression with its double-precision sqrt)
 __device__ inline float telea_estimate(float Ia, float Jx, float Jy, float s)
 {
     return (float)((double)__fdiv_rn(Ia, s) +
