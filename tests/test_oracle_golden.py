@@ -138,7 +138,7 @@ def test_oracle_tail_on_full_stored_bundles():
 def test_fft_precision_modes_agree():
     """The reference calls np.fft.fft2 on a float32 array and pins no NumPy version: NumPy < 2 transforms in complex128, NumPy >= 2 in
     complex64.  The oracle takes complex128 (ftp_oracle.FFT_COMPLEX128); this test measures how far the reference's two generations are
-    apart on the same frames -- the demodulated field agrees to complex64 rounding (a few 1e-7 of its scale), the final maps typically to
+    apart on the same frames -- the demodulated field agrees to ~1e-5 of its scale, the amplitude product to complex64 rounding, the final maps typically to
     1e-6 of their peak (up to ~1e-4 where a pixel sits on a hard threshold: the reference is only reproducible to that level across NumPy
     versions), the arg-max contact index is the same."""
     import importlib
@@ -161,7 +161,7 @@ def test_fft_precision_modes_agree():
     assert abs(pa[0] - pb[0]) < 1e-4 and abs(pa[1] - pb[1]) < 1e-4            # float32 log-parabolic refinement under complex64
     for a, b in zip(res[True][1], res[False][1]):
         fa, fb = a["inter"]["demod"]["field"], b["inter"]["demod"]["field"]
-        assert np.abs(fa - fb).max() <= 2e-6 * np.abs(fa).max()
+        assert np.abs(fa - fb).max() <= 3e-5 * np.abs(fa).max()          # incl. the phase ramp of a 1e-5 px difference in the refined carrier
         qa, qb = a["inter"]["quality"], b["inter"]["quality"]
         assert 0 < np.abs(qa - qb).max() <= 2e-6 * qa.max()                   # NOT identical: the two generations differ by float32 rounding noise
         assert int((a["reliable"] != b["reliable"]).sum()) <= 4
