@@ -368,3 +368,30 @@ def test_phase_to_height_fit_reproduces_the_stored_model(pkg, tmp_path):
         C.phase_to_height_model([{"file": "a", "depth_mm": 1.0, "min_height_unitless": float("nan")},
                                  {"file": "b", "depth_mm": 2.0, "min_height_unitless": -1.0}], "", "", "")
     assert pkg.FtpConfig.phase_to_height().roi_erode_px == 80 and pkg.FtpConfig.phase_to_height().plane_order_for_removal == 0
+
+
+def test_multimodal_summary_reproduces_the_stored_file(pkg, tmp_path):
+    """N1 remainder: combined_outputs/multimodal_summary.json (Code/multimodal_sensor.py:592-650).  From the readings of the stored FINAL_E
+    session and the four calibration JSONs of the reference tree (fixtures: data files), the writer gives the stored file back -- same keys,
+    same order, same values, byte for byte."""
+    stored_txt = open(os.path.join(G, "ref_multimodal_summary_FINAL_E.json"), encoding="utf-8").read()
+    stored = json.loads(stored_txt)
+    load = lambda f: json.load(open(os.path.join(G, f), encoding="utf-8"))
+    f, t = stored["sensor_readings"]["force"], stored["sensor_readings"]["temperature"]
+    res = {"force_N": f["force_N"], "volume_cm3": f["volume_cm3"], "contact_area_mm2": f["contact_area_mm2"], "max_depth_mm": f["max_depth_mm"],
+           "mm_per_px": f["scale_mm_per_px"]}
+    s = pkg.multimodal_summary(stored["session_id"], stored["timestamp"], stored["input_images"]["reference"], stored["input_images"]["deformed"],
+                               stored["output_directory"], res, t, load("calibration_phase_to_height.json"), load("calibration_height_to_force.json"),
+                               load("ref_temp_color_metrics.json"), load("ref_temp_black_metrics.json"), stored["file_paths"]["force_subdir"],
+                               stored["file_paths"]["temperature_subdir"], stored["file_paths"]["combined_subdir"])
+    assert s == stored
+    path = pkg.write_multimodal_summary(str(tmp_path), s)
+    assert open(path, encoding="utf-8").read() == stored_txt
+    # a missing calibration file gives an empty block, as upstream's load_json_safe -> None does
+    s2 = pkg.multimodal_summary("x", "y", "r", "d", "o", res, t, None, None, None, None, "a", "b", "c")
+    assert s2["calibration_performance"] == {"phase_to_height": {}, "height_to_force": {}, "temperature_color_model": {}, "temperature_black_model": {}}
+    # temperature statistics block (multimodal_sensor.py:558-567)
+    tm = np.array([[20.0, 21.0], [np.nan, 25.0]], np.float32)
+    st = pkg.temperature_statistics(tm, np.isfinite(tm))
+    assert list(st) == ["mean_C", "median_C", "std_C", "min_C", "max_C", "valid_pixels"] and st["valid_pixels"] == 3 and st["median_C"] == 21.0
+    assert np.isnan(pkg.temperature_statistics(tm, np.zeros((2, 2), bool))["mean_C"])

@@ -13,8 +13,10 @@ from . import synth
 from . import parallel
 from .align import FtpAligner, circle_from_3_points
 from . import calibrate
-from .writers import (export_heightmap_files, height_map_bundle, result_record, write_result_csv, write_result_json)
+from .writers import (export_heightmap_files, height_map_bundle, multimodal_summary, result_record, temperature_statistics,
+                      write_multimodal_summary, write_result_csv, write_result_json)
 
 __all__ = ["FtpConfig", "FtpSensor", "SCALAR_NAMES", "depth_map_to_volume_cm3", "estimate_mm_per_px", "load_calibration",
            "load_force_calibration", "predict", "predict_force_from_volume", "synth", "parallel", "FtpAligner", "circle_from_3_points", "calibrate", "_lib", "export_heightmap_files",
-           "height_map_bundle", "result_record", "write_result_csv", "write_result_json"]
+           "height_map_bundle", "result_record", "write_result_csv", "write_result_json", "multimodal_summary", "temperature_statistics",
+           "write_multimodal_summary"]

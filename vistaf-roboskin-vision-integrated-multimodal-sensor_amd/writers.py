@@ -7,6 +7,9 @@
   `height_crop`, `height_full`, seven `crop_*` and seven `full_*` boolean masks and ten `meta_*` int32 scalars, so the
   bundles the reference stored can be diffed key by key against the ones written from the GPU path.
 
+* `multimodal_summary` / `write_multimodal_summary` -- `Code/multimodal_sensor.py:592-650` with its metric extractors (:214-280): the
+  `multimodal_summary.json` of a combined force + temperature session (same keys, order and nesting).
+
 These functions take NumPy arrays (what `FtpSensor.predict` / `FtpSensor.masks` return); nothing here touches the GPU.
 """
 from __future__ import annotations
@@ -128,3 +131,97 @@ def export_heightmap_files(output_dir: str, bundle: Mapping[str, np.ndarray], ba
         np.savetxt(paths["full_csv"], bundle["height_full"].astype(np.float32), delimiter=",", fmt="%.9g")
     np.savez_compressed(paths["bundle_npz"], **{k: np.asarray(v) for k, v in bundle.items()})
     return paths
+
+
+# ---- multimodal_summary.json (Code/multimodal_sensor.py:592-650) ------------------------------------------------------------------
+def _nan_float(x) -> float:
+    """multimodal_sensor.safe_float (:95-102): float(x) if finite else NaN"""
+    return _safe_float(x, float("nan"))
+
+
+def _phase_to_height_metrics(calib: Optional[Mapping[str, Any]]) -> Dict[str, Any]:
+    """extract_phase_to_height_metrics (:214-227)"""
+    if calib is None:
+        return {}
+    best = calib.get("best_model", {})
+    return {"calibration_type": "phase_to_height", "model_type": best.get("type", "unknown"), "equation": best.get("equation", ""),
+            "r2": _nan_float(best.get("r2", float("nan"))), "rmse": _nan_float(best.get("rmse", float("nan"))),
+            "n_samples": int(best.get("n", 0)), "x_definition": calib.get("x_definition", "")}
+
+
+def _height_to_force_metrics(calib: Optional[Mapping[str, Any]]) -> Dict[str, Any]:
+    """extract_height_to_force_metrics (:229-243)"""
+    if calib is None:
+        return {}
+    best = calib.get("best_model", {})
+    return {"calibration_type": "height_to_force", "model_type": best.get("type", "unknown"), "equation": best.get("equation", ""),
+            "r2": _nan_float(best.get("r2", float("nan"))), "rmse": _nan_float(best.get("rmse", float("nan"))),
+            "n_fit": int(best.get("n_fit", 0)), "n_samples": int(best.get("n_samples", 0)),
+            "volume_definition": calib.get("volume_definition", "")}
+
+
+def _temp_model_metrics(calib: Optional[Mapping[str, Any]], model_name: str) -> Dict[str, Any]:
+    """extract_temp_model_metrics (:245-280)"""
+    if calib is None:
+        return {}
+    models = calib.get("models_final", {})
+    if model_name not in models:
+        return {}
+    m = models[model_name]
+
+    def block(d):
+        return {"rmse_C": _nan_float(d.get("rmse_C", float("nan"))), "mae_C": _nan_float(d.get("mae_C", float("nan"))),
+                "r2": _nan_float(d.get("r2", float("nan"))), "max_abs_err_C": _nan_float(d.get("max_abs_err_C", float("nan"))),
+                "p95_abs_err_C": _nan_float(d.get("p95_abs_err_C", float("nan"))), "n": int(d.get("n", 0))}
+    return {"model": model_name, "degree": int(m.get("degree", 0)), "equation": m.get("equation", ""),
+            "frames": block(m.get("metrics_frames", {})), "means": block(m.get("metrics_means", {}))}
+
+
+def temperature_statistics(temp_map_C, valid_mask) -> Dict[str, Any]:
+    """mean / median / std / min / max of the final temperature map over its valid pixels (multimodal_sensor.py:558-567), in the key order
+    of the summary's `temperature` block; NaN statistics when no pixel is valid."""
+    t = np.asarray(temp_map_C)
+    valid = np.asarray(valid_mask, dtype=bool)
+    if np.any(valid):
+        v = t[valid]
+        st = {"mean_C": float(np.mean(v)), "median_C": float(np.median(v)), "std_C": float(np.std(v)), "min_C": float(np.min(v)),
+              "max_C": float(np.max(v))}
+    else:
+        st = {k: float("nan") for k in ("mean_C", "median_C", "std_C", "min_C", "max_C")}
+    st["valid_pixels"] = int(np.count_nonzero(valid))
+    return st
+
+
+def multimodal_summary(session_id: str, timestamp: str, reference_image: str, deformed_image: str, session_dir: str, force: Mapping[str, Any],
+                       temperature: Mapping[str, Any], p2h_calib: Optional[Mapping[str, Any]], h2f_calib: Optional[Mapping[str, Any]],
+                       color_calib: Optional[Mapping[str, Any]], black_calib: Optional[Mapping[str, Any]], force_subdir: str,
+                       temp_subdir: str, combined_subdir: str) -> Dict[str, Any]:
+    """The dict `multimodal_sensor.main` dumps to combined_outputs/multimodal_summary.json (:592-644).  `force`: what `FtpSensor.predict`
+    returned (force_N, volume_cm3, contact_area_mm2, max_depth_mm, mm_per_px); `temperature`: `temperature_statistics(...)`; the four
+    calibration dicts are the loaded calibration JSONs (None when a file is missing, as upstream's load_json_safe returns)."""
+    return {
+        "session_id": session_id,
+        "timestamp": timestamp,
+        "input_images": {"reference": reference_image, "deformed": deformed_image},
+        "output_directory": session_dir,
+        "sensor_readings": {
+            "force": {"force_N": force["force_N"], "volume_cm3": force["volume_cm3"], "contact_area_mm2": force["contact_area_mm2"],
+                      "max_depth_mm": force["max_depth_mm"], "scale_mm_per_px": force["mm_per_px"]},
+            "temperature": {k: temperature[k] for k in ("mean_C", "median_C", "std_C", "min_C", "max_C", "valid_pixels")},
+        },
+        "calibration_performance": {
+            "phase_to_height": _phase_to_height_metrics(p2h_calib),
+            "height_to_force": _height_to_force_metrics(h2f_calib),
+            "temperature_color_model": {k: _temp_model_metrics(color_calib, k) for k in ("heating", "cooling", "global")} if color_calib else {},
+            "temperature_black_model": {k: _temp_model_metrics(black_calib, k) for k in ("heating", "cooling", "global")} if black_calib else {},
+        },
+        "file_paths": {"force_subdir": force_subdir, "temperature_subdir": temp_subdir, "combined_subdir": combined_subdir},
+    }
+
+
+def write_multimodal_summary(combined_subdir: str, summary: Mapping[str, Any]) -> str:
+    os.makedirs(combined_subdir, exist_ok=True)
+    path = os.path.join(combined_subdir, "multimodal_summary.json")
+    with open(path, "w", encoding="utf-8") as f:
+        json.dump(summary, f, indent=2)                      # :648-649
+    return path
