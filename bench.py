@@ -131,6 +131,20 @@ def timed_steps(stepper, warmup, steps, dist, sync, dev):
     return elapsed
 
 
+MFMA_F64_PEAK_TFLOPS = 78.6     # MI355X_MICROARCH.md: FP64 matrix (= FP64 vector) peak
+
+
+def _dft_gemm_record(stage_ms, B, n, sensor, demods):
+    cfg = sensor.config
+    pw = 2 * max(3, int(cfg.patch_half_width_bins)) + 1
+    fwd = 2.0 * (B * n) * n * (2 * pw)                 # [B*h x w] . [w x 2pw]
+    inv = 2.0 * 2.0 * (B * n * n) * (2 * pw)           # [h x 2ph] . [2ph x {re, im} w] per frame
+    flops = demods * (fwd + inv)
+    tf = flops / (stage_ms * 1e-3) / 1e12 if stage_ms > 0 else 0.0
+    return {"kernels": ["k_dft_fwd1_mfma", "k_dft_inv2_mfma"], "dtype": "f64", "flops_per_step": flops, "stage_ms": round(stage_ms, 4),
+            "achieved_TFLOPs_over_stage": round(tf, 3), "peak_TFLOPs": MFMA_F64_PEAK_TFLOPS, "frac_of_mfma_peak_over_stage": round(tf / MFMA_F64_PEAK_TFLOPS, 4)}
+
+
 def _csrc_sha():
     """fingerprint of the kernel sources: recorded by tools/collect_profiles.py next to the PMC traffic numbers, so that a traffic figure
     measured on other kernels is never reported as this run's"""
@@ -305,6 +319,10 @@ def main():
                 "note": "dominant stage is latency-bound (a sequential fast-marching / priority-queue march, one wave per frame), not bandwidth-bound",
                 "other_heavy_stages": other,
             },
+            # the one dense contraction of the path: the pruned-DFT stages 1 and 4 as float64 GEMMs on the matrix cores (v_mfma_f64_16x16x4_f64).
+            # FLOPs of the two MFMA kernels over the WHOLE demodulation stage's event time (a lower bound on the kernels' own utilisation: the
+            # stage also holds the two small non-MFMA stages and the amplitude / atan2 epilogue; per-kernel times: profiles/*_kernel_table.txt)
+            "dft_gemm": _dft_gemm_record(acc.get("pruned-dft demod", 0.0), B, n, sensor, 2 if args.pairs else 1),
             "stage_ms": {k: round(v, 4) for k, v in acc.items()},
             "serial_ms_per_step": round(sum(acc.values()), 4),
         }

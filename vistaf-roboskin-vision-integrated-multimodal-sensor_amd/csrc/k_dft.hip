@@ -61,6 +61,59 @@ __global__ __launch_bounds__(256) void k_dft_fwd1(const float *__restrict__ iw, 
         if (rg * DFT_RR + k < nr) T[(b * (size_t)h + y0 + rg * DFT_RR + k) * pw + c] = make_double2(ar[k], ai[k]);
 }
 
+// stage 1 as a float64 GEMM on the matrix cores: C[row = (b, y)][n] = sum_x V[row][x] * E[x][n], n = 0..2*pw-1 (real parts of the pw bins,
+// then their imaginary parts), with v_mfma_f64_16x16x4_f64: A[i = lane & 15][k = lane >> 4] = V, B[k = lane >> 4][j = lane & 15] = E,
+// D[row = (lane >> 4) + 4 * reg][col = lane & 15].  One wave owns a strip of 16 image rows and all column tiles (<= DFT_MAXT at a time);
+// operands come straight from global memory / L2 (the table is 2 * pw * w doubles), one element per lane and k-step.  This is the only dense
+// contraction of the path; float64 keeps the accumulation the parity of the demodulated field relies on.
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+constexpr int DFT_MAXT = 4;            // column tiles (16 columns each) accumulated per pass over x
+__global__ __launch_bounds__(256) void k_dft_fwd1_mfma(const float *__restrict__ iw, const float *__restrict__ mu, const double2 *__restrict__ Ex_all,
+                                                       size_t ex_stride, double2 *__restrict__ T, int h, int w, int pw, int rows_total)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int row0 = (blockIdx.x * 4 + wid) * 16;
+    if (row0 >= rows_total) return;
+    const int r = lane & 15, kk = lane >> 4;
+    const int grow = min(row0 + r, rows_total - 1);            // rows past the end repeat the last one (never stored)
+    const size_t b = (size_t)(row0 / h);                       // a strip never straddles frames in the table choice: h % 16 == 0 is required
+    const double *E = (const double *)(Ex_all + b * ex_stride);
+    const float *src = iw + (size_t)grow * w;
+    const float m = mu ? mu[grow / h] : 0.f;
+    const int ncol = 2 * pw, ntile = (ncol + 15) / 16;
+    for (int t0 = 0; t0 < ntile; t0 += DFT_MAXT) {
+        v4f64 acc[DFT_MAXT];
+        int eoff[DFT_MAXT];                                     // offset of this lane's column inside one table row (doubles), -1: padding column
+#pragma unroll
+        for (int t = 0; t < DFT_MAXT; t++) {
+            acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+            const int n = (t0 + t) * 16 + r;
+            eoff[t] = (t0 + t < ntile && n < ncol) ? (n < pw ? 2 * n : 2 * (n - pw) + 1) : -1;
+        }
+        for (int x0 = 0; x0 < w; x0 += 4) {
+            const int x = x0 + kk;
+            const bool in = x < w;
+            const double a = in ? (double)__fsub_rn(src[in ? x : 0], m) : 0.0;
+            double bv[DFT_MAXT];
+#pragma unroll
+            for (int t = 0; t < DFT_MAXT; t++) bv[t] = (in && eoff[t] >= 0) ? E[(size_t)x * (2 * pw) + eoff[t]] : 0.0;
+#pragma unroll
+            for (int t = 0; t < DFT_MAXT; t++)
+                if (t0 + t < ntile) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[t], acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < DFT_MAXT; t++) {
+            if (eoff[t] < 0) continue;
+            const int n = (t0 + t) * 16 + r, c = n < pw ? n : n - pw;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int row = row0 + kk + 4 * q;
+                if (row < rows_total) ((double *)(T + (size_t)row * pw + c))[n < pw ? 0 : 1] = acc[t][q];
+            }
+        }
+    }
+}
+
 // stage 2: patch[b, a, c] = win[a,c] * sum_y Ey[a, y] * T[b, y, c]   (complex128 spectrum value times the float32 window, as upstream's
 // `patch *= win` under complex128: both parts times the window in float64)
 __global__ void k_dft_fwd2(const double2 *__restrict__ T, const double2 *__restrict__ Ey_all, size_t ey_stride, const float *__restrict__ win,
@@ -98,8 +151,13 @@ void launch_dft_forward(const float *iw, const float *mu, const double2 *Ex, con
     const int rb_lds = (int)((60 * 1024) / ((size_t)DFT_RR * w * sizeof(float)));     // staged rows must fit the default dynamic LDS limit
     if (rb > rb_lds) rb = rb_lds;
     if (rb < 1) rb = 1;
-    dim3 g1((h + rb * DFT_RR - 1) / (rb * DFT_RR), B);
-    hipLaunchKernelGGL(k_dft_fwd1, g1, dim3(256), (size_t)rb * DFT_RR * w * sizeof(float), st, iw, mu, Ex, tab_stride_x, tmpT, h, w, pw, rb);
+    if (h % 16 == 0) {      // matrix-core form: strips of 16 rows inside one frame (one table per strip)
+        const int rows = B * h;
+        hipLaunchKernelGGL(k_dft_fwd1_mfma, dim3((rows / 16 + 3) / 4), dim3(256), 0, st, iw, mu, Ex, tab_stride_x, tmpT, h, w, pw, rows);
+    } else {
+        dim3 g1((h + rb * DFT_RR - 1) / (rb * DFT_RR), B);
+        hipLaunchKernelGGL(k_dft_fwd1, g1, dim3(256), (size_t)rb * DFT_RR * w * sizeof(float), st, iw, mu, Ex, tab_stride_x, tmpT, h, w, pw, rb);
+    }
     hipLaunchKernelGGL(k_dft_fwd2, dim3(B), dim3(std::min(1024, ((ph * pw + 63) / 64) * 64)), 0, st, (const double2 *)tmpT, Ey, tab_stride_y, win, patch, h, ph, pw,
                        patch_stride);
 }
@@ -175,13 +233,75 @@ __global__ __launch_bounds__(256) void k_dft_inv2(const double2 *__restrict__ Q,
     }
 }
 
+// stage 4 on the matrix cores.  The complex product field = Gy . Q is the real float64 GEMM  [re | im] = [Gr | Gi] . [[Qr, Qi], [-Qi, Qr]]
+// with K = 2 * ph: A[y][k] = Gr[y][k] for k < ph, Gi[y][k - ph] above; one double2 of Q per lane and k-step gives both B operands
+// ((q.x, q.y) below ph, (-q.y, q.x) above).  A wave owns 16 rows x 64 columns of one frame (four column tiles x {re, im} accumulators), a
+// workgroup four such strips; the epilogue is that of k_dft_inv2 (re and im of an element sit in the same lane and register index).
+__global__ __launch_bounds__(256) void k_dft_inv2_mfma(const double2 *__restrict__ Q, const double2 *__restrict__ Gy_all, size_t gy_stride,
+                                                       double2 *__restrict__ field, float *__restrict__ amp, const double2 *__restrict__ cref_all,
+                                                       const float *__restrict__ amp_ref_all, size_t ref_stride, float *__restrict__ prod,
+                                                       float *__restrict__ wrapped, int h, int w, int ph)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int x0 = blockIdx.x * 64, y0 = (blockIdx.y * 4 + wid) * 16;
+    const size_t b = blockIdx.z;
+    if (y0 >= h) return;
+    const int r = lane & 15, kk = lane >> 4;
+    const double *G = (const double *)(Gy_all + b * gy_stride);
+    const double2 *Qb = Q + b * (size_t)ph * w;
+    const int ya = min(y0 + r, h - 1);
+    v4f64 cre[4], cim[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) { cre[t] = (v4f64){0.0, 0.0, 0.0, 0.0}; cim[t] = (v4f64){0.0, 0.0, 0.0, 0.0}; }
+    const int K = 2 * ph;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const int k = k0 + kk;
+        const bool in = k < K, hi = k >= ph;
+        const int kq = in ? (hi ? k - ph : k) : 0;
+        const double a = in ? G[((size_t)ya * ph + kq) * 2 + (hi ? 1 : 0)] : 0.0;
+        double2 q[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) q[t] = Qb[(size_t)kq * w + min(x0 + 16 * t + r, w - 1)];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const double bre = in ? (hi ? -q[t].y : q[t].x) : 0.0, bim = in ? (hi ? q[t].x : q[t].y) : 0.0;
+            cre[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bre, cre[t], 0, 0, 0);
+            cim[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bim, cim[t], 0, 0, 0);
+        }
+    }
+    const double2 *cref = cref_all ? cref_all + b * ref_stride : nullptr;
+    const float *amp_ref = amp_ref_all ? amp_ref_all + b * ref_stride : nullptr;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int x = x0 + 16 * t + r;
+        if (x >= w) continue;
+#pragma unroll
+        for (int qd = 0; qd < 4; qd++) {
+            const int y = y0 + kk + 4 * qd;
+            if (y >= h) continue;
+            const double ar = cre[t][qd], ai = cim[t][qd];
+            const size_t p = (size_t)y * w + x, i = b * (size_t)h * w + p;
+            if (field) field[i] = make_double2(ar, ai);
+            const float am = (float)sqrt(fma(ar, ar, ai * ai));
+            amp[i] = am;
+            if (cref) {
+                const double2 c = cref[p];
+                const double rr = ar * c.x + ai * c.y;
+                const double ri = ai * c.x - ar * c.y;
+                wrapped[i] = (float)atan2(ri, rr);
+                prod[i] = __fmul_rn(amp_ref[p], am);
+            }
+        }
+    }
+}
+
 void launch_dft_inverse(const double2 *patch, int patch_stride, const double2 *Gx, const double2 *Gy, size_t tab_stride_x, size_t tab_stride_y,
                         double2 *tmpQ, double2 *field, float *amp, const double2 *cref, const float *amp_ref, size_t ref_stride, float *prod,
                         float *wrapped, int B, int h, int w, int ph, int pw, hipStream_t st)
 {
     hipLaunchKernelGGL(k_dft_inv1, dim3((w + 255) / 256, ph, B), dim3(256), 0, st, patch, patch_stride, Gx, tab_stride_x, tmpQ, w, ph, pw);
-    hipLaunchKernelGGL(k_dft_inv2, dim3((w + 255) / 256, (h + DFT_RY - 1) / DFT_RY, B), dim3(256), (size_t)DFT_RY * ph * sizeof(double2), st,
-                       (const double2 *)tmpQ, Gy, tab_stride_y, field, amp, cref, amp_ref, ref_stride, prod, wrapped, h, w, ph);
+    hipLaunchKernelGGL(k_dft_inv2_mfma, dim3((w + 63) / 64, (h + 63) / 64, B), dim3(256), 0, st, (const double2 *)tmpQ, Gy, tab_stride_y, field, amp, cref,
+                       amp_ref, ref_stride, prod, wrapped, h, w, ph);
 }
 
 // ---- full spectrum magnitude (reference-frame carrier search, shape_ftp.py:867-872), float64 as np.abs(fft2(float64)) ----
