@@ -322,7 +322,7 @@ def main():
             # the one dense contraction of the path: the pruned-DFT stages 1 and 4 as float64 GEMMs on the matrix cores (v_mfma_f64_16x16x4_f64).
             # FLOPs of the two MFMA kernels over the WHOLE demodulation stage's event time (a lower bound on the kernels' own utilisation: the
             # stage also holds the two small non-MFMA stages and the amplitude / atan2 epilogue; per-kernel times: profiles/*_kernel_table.txt)
-            "dft_gemm": _dft_gemm_record(acc.get("pruned-dft demod", 0.0), B, n, sensor, 2 if args.pairs else 1),
+            "dft_gemm": _dft_gemm_record(acc.get("pruned-dft demod", 0.0), B, n, sensor, 1),
             "stage_ms": {k: round(v, 4) for k, v in acc.items()},
             "serial_ms_per_step": round(sum(acc.values()), 4),
         }
