@@ -1,0 +1,68 @@
+/* vistaf_temp.h -- C ABI of the first slice of the temperature modality, part of libvistaf_ftp.so.
+ *
+ * Replaces, on the MI355X, the periodic-stripe segmentation of the reference's temperature module -- the step that splits the
+ * thermochromic grating of a full photograph into its dark and its light stripes before any regression runs:
+ *
+ *   vistaf_tempseg_segment     Code/temperature_sensor.py:437-540 `segment_dark_light_gratings_periodic_fft(image_bgr, roi_full)`
+ *                              with its helpers _make_saturation_mask (:378-387), _illum_normalize (:363-375), _find_top_peaks (:316-337),
+ *                              _choose_carrier_peak (:339-360) and _postprocess_mask (:390-406)
+ *
+ * The temperature regressors themselves (TempModel.predict, :236) are NOT here: their parameters only exist as pickled scikit-learn
+ * pipelines (.joblib).  All image pointers are HIP device pointers; `stream` is a hipStream_t passed as void*.  Every function returns 0
+ * or a negative VISTAF_E_* code (vistaf_ftp.h); vistaf_ftp_last_error() holds the message.  The full-frame spectrum of the carrier search
+ * is a plain library transform (hipFFT, float32: only the POSITION of the strongest peaks is read from it); the band-pass around the chosen
+ * carrier is the library's own pruned float64 DFT on the matrix cores, everything else hand-written HIP.
+ */
+#ifndef VISTAF_TEMP_H
+#define VISTAF_TEMP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vistaf_tempseg_handle vistaf_tempseg_handle;
+
+typedef struct vistaf_tempseg_config {   /* Code/temperature_sensor.py:67-82, defaults as shipped */
+    int32_t seg_band_radius;             /* :67 22  */
+    int32_t seg_dc_exclusion;            /* :68 28  */
+    int32_t seg_illum_sigma;             /* :72 20 (0 disables the Gaussian illumination normalisation) */
+    int32_t sat_thresh_gray;             /* :75 245 */
+    int32_t sat_dilate_ksize;            /* :76 13  */
+    int32_t post_close_kx, post_close_ky;/* :79-80 3, 31 */
+    int32_t post_open_kx, post_open_ky;  /* :81-82 3, 7 */
+    int32_t n_peaks;                     /* :457 16 */
+    double seg_peak_max_dy_from_center;  /* :71 0.14 */
+} vistaf_tempseg_config;
+
+/* record returned by vistaf_tempseg_segment (the `dbg` dict of :513-527), doubles */
+#define VISTAF_TEMPSEG_NINFO 16
+#define VISTAF_TS_PEAK_X 0
+#define VISTAF_TS_PEAK_Y 1
+#define VISTAF_TS_PHI0_RAD 2
+#define VISTAF_TS_MEAN_GRAY_A 3
+#define VISTAF_TS_MEAN_GRAY_B 4
+#define VISTAF_TS_A_IS_DARK 5
+#define VISTAF_TS_ROI_PIXELS 6
+#define VISTAF_TS_ROI_EFF_PIXELS 7
+#define VISTAF_TS_SAT_PIXELS 8
+#define VISTAF_TS_DARK_PIXELS 9
+#define VISTAF_TS_LIGHT_PIXELS 10
+#define VISTAF_TS_CARRIER_ANGLE_RAD 11
+#define VISTAF_TS_CARRIER_PERIOD_PX 12
+
+int vistaf_tempseg_default_config(vistaf_tempseg_config *cfg);
+int vistaf_tempseg_create(const vistaf_tempseg_config *cfg, int H, int W, vistaf_tempseg_handle **out);
+void vistaf_tempseg_destroy(vistaf_tempseg_handle *h);
+
+/* d_bgr [H,W,3] uint8 (cv2.imread order), d_roi [H,W] uint8 0/1 (roi_full).  Outputs [H,W] uint8 0/1, any may be NULL:
+ * d_dark / d_light (dark_final, light_final), d_roi_eff, d_sat; info_host[VISTAF_TEMPSEG_NINFO] on the HOST.
+ * Errors as upstream: VISTAF_E_STATE when the ROI is empty after the saturation exclusion (:445-446).  Synchronises `stream`. */
+int vistaf_tempseg_segment(vistaf_tempseg_handle *h, const uint8_t *d_bgr, const uint8_t *d_roi, uint8_t *d_dark, uint8_t *d_light,
+                           uint8_t *d_roi_eff, uint8_t *d_sat, double *info_host, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,192 @@
+"""CPU oracle for the first slice of the temperature modality.  TEST INFRASTRUCTURE ONLY.
+
+Restates /root/reference/Code/temperature_sensor.py's periodic-stripe segmentation -- the step that splits the thermochromic grating into its
+dark and light stripes before any temperature regression runs:
+
+  circle_from_three_points / roi_mask_from_circle  :156-183
+  bbox_from_mask / crop2d                           :194-216
+  _find_top_peaks / _choose_carrier_peak            :316-360
+  _illum_normalize                                  :363-375
+  _make_saturation_mask                             :378-387
+  _postprocess_mask                                 :390-406
+  segment_dark_light_gratings_periodic_fft          :437-540
+
+NumPy calls are the reference's; OpenCV calls (cvtColor BGR2GRAY, GaussianBlur, getStructuringElement ELLIPSE / RECT, dilate, morphologyEx
+CLOSE / OPEN) go through oracle/cvlite.c / oracle/align_oracle.py like everywhere else in this oracle.  FFT precision follows
+ftp_oracle.FFT_COMPLEX128 (see there).
+
+Pinned by the masks the reference itself stored for its five demo photographs
+(Multimodal_Sensor/Demos_report/<name>/temperature_sensing/mask_{roi,roi_eff,sat,dark,light}.png, written by temperature_sensor.py:803-812):
+tests/golden/make_temp_seg_report.py -> tests/golden/temp_seg_report.json, and the FINAL_E masks as a committed fixture.
+The temperature REGRESSORS (Huber pipelines stored as .joblib pickles) are out of reach of this build: pickles are not loadable under its
+rules and the equations_*.txt files list coefficients in standardised variables without the scaler.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Any, Dict, Tuple
+
+import numpy as np
+
+from . import align_oracle as A
+from . import cvlite as cv
+from . import ftp_oracle as O
+
+
+@dataclasses.dataclass
+class TempSegConfig:
+    """temperature_sensor.py:36-82 (as shipped)"""
+    outer_circle: Tuple[Tuple[int, int], Tuple[int, int], Tuple[int, int]] = ((1845, 1818), (1517, 623), (2687, 914))   # :37-39
+    crop_pad_px: int = 10                 # :49
+    seg_band_radius: int = 22             # :67
+    seg_dc_exclusion: int = 28            # :68
+    seg_peak_max_dy_from_center: float = 0.14   # :71
+    seg_illum_sigma: int = 20             # :72
+    sat_thresh_gray: int = 245            # :75
+    sat_dilate_ksize: int = 13            # :76
+    post_close_kx: int = 3                # :79
+    post_close_ky: int = 31               # :80
+    post_open_kx: int = 3                 # :81
+    post_open_ky: int = 7                 # :82
+    n_peaks: int = 16                     # :457
+
+
+def circle_from_three_points(p1, p2, p3, eps: float = 1e-12):
+    """:156-177"""
+    x1, y1 = map(float, p1)
+    x2, y2 = map(float, p2)
+    x3, y3 = map(float, p3)
+    a, b, c, d = x1 - x2, y1 - y2, x1 - x3, y1 - y3
+    e = (x1 ** 2 - x2 ** 2 + y1 ** 2 - y2 ** 2) / 2.0
+    f = (x1 ** 2 - x3 ** 2 + y1 ** 2 - y3 ** 2) / 2.0
+    det = a * d - b * c
+    if abs(det) < eps:
+        raise RuntimeError("Cannot define circle: points are collinear (or nearly collinear).")
+    cx = (d * e - b * f) / det
+    cy = (-c * e + a * f) / det
+    return float(cx), float(cy), float(np.hypot(x1 - cx, y1 - cy))
+
+
+def roi_mask_from_circle(h: int, w: int, p1, p2, p3) -> np.ndarray:
+    """:180-184"""
+    cx, cy, r = circle_from_three_points(p1, p2, p3)
+    yy, xx = np.ogrid[:h, :w]
+    return (xx - cx) ** 2 + (yy - cy) ** 2 <= r ** 2
+
+
+def bbox_from_mask(mask: np.ndarray, pad: int = 0):
+    """:194-208: (y0, y1, x0, x1), end exclusive"""
+    h, w = mask.shape[:2]
+    ys, xs = np.where(mask)
+    if ys.size == 0:
+        return 0, h, 0, w
+    return (int(max(0, ys.min() - int(pad))), int(min(h, ys.max() + int(pad) + 1)), int(max(0, xs.min() - int(pad))),
+            int(min(w, xs.max() + int(pad) + 1)))
+
+
+def _ensure_odd(k: int) -> int:
+    k = int(k)
+    return k if k % 2 == 1 else k + 1
+
+
+def _rect_se(kx: int, ky: int) -> np.ndarray:
+    """cv2.getStructuringElement(MORPH_RECT, (kx, ky)) embedded in the square element cvlite's morphology takes (anchor = centre both ways)"""
+    k = max(kx, ky)
+    se = np.zeros((k, k), np.uint8)
+    se[(k - ky) // 2:(k - ky) // 2 + ky, (k - kx) // 2:(k - kx) // 2 + kx] = 1
+    return se
+
+
+def make_saturation_mask(gray_u8: np.ndarray, roi: np.ndarray, cfg: TempSegConfig) -> np.ndarray:
+    """:378-387"""
+    sat = (gray_u8 >= int(cfg.sat_thresh_gray)) & roi
+    k = _ensure_odd(cfg.sat_dilate_ksize)
+    if k > 1 and np.any(sat):
+        sat = (cv.dilate(sat.astype(np.uint8) * 255, cv.ellipse_se(k), 1) > 127) & roi
+    return sat
+
+
+def illum_normalize(gray_f: np.ndarray, roi: np.ndarray, sigma: int) -> np.ndarray:
+    """:363-375"""
+    g = gray_f.astype(np.float32)
+    if sigma is None or int(sigma) <= 0:
+        mu = float(np.mean(g[roi])) if np.any(roi) else float(np.mean(g))
+        mu = mu if abs(mu) > 1e-9 else 1.0
+        return (g / mu).astype(np.float32)
+    blur = cv.gaussian_blur(g, float(sigma))
+    blur[blur < 1e-6] = 1.0
+    norm = g / blur
+    mu = float(np.mean(norm[roi])) if np.any(roi) else float(np.mean(norm))
+    mu = mu if abs(mu) > 1e-9 else 1.0
+    return (norm / mu).astype(np.float32)
+
+
+def postprocess_mask(m: np.ndarray, roi: np.ndarray, cfg: TempSegConfig) -> np.ndarray:
+    """:390-406: close (kx x ky rectangle) then open, inside roi"""
+    if not np.any(m):
+        return m
+    k_close = _rect_se(_ensure_odd(max(1, cfg.post_close_kx)), _ensure_odd(max(1, cfg.post_close_ky)))
+    k_open = _rect_se(_ensure_odd(max(1, cfg.post_open_kx)), _ensure_odd(max(1, cfg.post_open_ky)))
+    mu8 = m.astype(np.uint8) * 255
+    mu8 = cv.erode(cv.dilate(mu8, k_close, 1), k_close, 1)        # MORPH_CLOSE
+    mu8 = cv.dilate(cv.erode(mu8, k_open, 1), k_open, 1)          # MORPH_OPEN
+    return (mu8 > 127) & roi
+
+
+def choose_carrier_peak(peaks, h: int, w: int, max_dy_frac: float):
+    """:339-360 (SEG_FORCE_RIGHT_HALF_PLANE and SEG_PREFER_PEAK_NEAR_CENTER_ROW both True)"""
+    return O.choose_carrier_peak(peaks, h, w, max_dy_frac)
+
+
+def segment_dark_light_gratings_periodic_fft(image_bgr: np.ndarray, roi_full: np.ndarray, cfg: TempSegConfig = TempSegConfig()):
+    """:437-540 -> (dark_final, light_final, pack)"""
+    h, w = image_bgr.shape[:2]
+    gray_u8 = A.bgr2gray_u8(image_bgr)
+    gray = gray_u8.astype(np.float32)
+    sat = make_saturation_mask(gray_u8, roi_full, cfg)
+    roi_eff = roi_full & (~sat)
+    if not np.any(roi_eff):
+        raise RuntimeError("ROI became empty after saturation exclusion. Lower SAT_THRESH_GRAY / dilation.")
+    g = gray.copy()
+    med = float(np.median(g[roi_eff]))
+    g[~roi_full] = med
+    i_norm = illum_normalize(g, roi_eff, cfg.seg_illum_sigma)
+    F = np.fft.fft2(i_norm.astype(np.float64) if O.FFT_COMPLEX128 else i_norm)
+    F_shift = np.fft.fftshift(F)
+    mag = np.abs(F_shift)
+    peaks = O.find_top_peaks(mag, dc_exclusion=int(cfg.seg_dc_exclusion), n_peaks=cfg.n_peaks)
+    if not peaks:
+        raise RuntimeError("Could not find FFT peaks for stripe carrier.")
+    peak_x, peak_y = choose_carrier_peak(peaks, h, w, cfg.seg_peak_max_dy_from_center)
+    yy, xx = np.ogrid[:h, :w]
+    bp = (xx - peak_x) ** 2 + (yy - peak_y) ** 2 <= float(cfg.seg_band_radius) ** 2
+    z = np.fft.ifft2(np.fft.ifftshift(F_shift * bp))
+    m = (i_norm - 1.0).astype(np.float32)
+    c = np.sum(z[roi_eff] * m[roi_eff])
+    phi0 = float(np.angle(c)) if np.isfinite(c) else 0.0
+    z_rot = z * np.exp(-1j * phi0)
+    s = np.real(z_rot).astype(np.float32)
+    mask_a = (s >= 0) & roi_eff
+    mask_b = (s < 0) & roi_eff
+    mean_a = float(np.mean(gray[mask_a])) if np.any(mask_a) else 1e9
+    mean_b = float(np.mean(gray[mask_b])) if np.any(mask_b) else 1e9
+    if mean_a <= mean_b:
+        dark, light, chosen = mask_a, mask_b, "A_is_dark"
+    else:
+        dark, light, chosen = mask_b, mask_a, "B_is_dark"
+    raw_dark = dark
+    dark = postprocess_mask(dark, roi_eff, cfg)
+    dark_final = dark & roi_eff
+    light_final = roi_eff & (~dark_final)
+    cy, cx = h // 2, w // 2
+    dx, dy = float(peak_x - cx), float(peak_y - cy)
+    fmag = float(np.hypot(dx / float(w), dy / float(h)))
+    dbg: Dict[str, Any] = {
+        "peak_x": int(peak_x), "peak_y": int(peak_y), "phi0_rad": float(phi0), "mean_gray_A": mean_a, "mean_gray_B": mean_b, "chosen": chosen,
+        "roi_pixels": int(np.count_nonzero(roi_full)), "roi_eff_pixels": int(np.count_nonzero(roi_eff)), "sat_pixels": int(np.count_nonzero(sat)),
+        "dark_pixels": int(np.count_nonzero(dark_final)), "light_pixels": int(np.count_nonzero(light_final)),
+        "carrier_angle_rad": float(np.arctan2(dy, dx)), "carrier_period_px": (1.0 / fmag) if fmag > 1e-9 else float("nan"),
+    }
+    pack = {"dbg": dbg, "fft_mag": mag, "signal": s, "roi_eff": roi_eff, "sat": sat, "peak": (peak_x, peak_y), "angle_rad": dbg["carrier_angle_rad"],
+            "period_px": dbg["carrier_period_px"], "raw_dark": raw_dark, "i_norm": i_norm, "z": z}
+    return dark_final, light_final, pack

@@ -28,6 +28,11 @@ def test_library_exports_every_declared_symbol(pkg):
     for name in declared2:
         assert hasattr(lib, name), name
     assert sorted(pkg._lib.ALIGN_EXPORTS) == declared2
+    hdr3 = open(os.path.join(ROOT, "include", "vistaf_temp.h")).read()
+    declared3 = sorted(set(re.findall(r"\b(vistaf_tempseg_\w+)\s*\(", hdr3)))
+    assert len(declared3) == 4 and sorted(pkg._lib.TEMP_EXPORTS) == declared3
+    for name in declared3:
+        assert hasattr(lib, name), name
 
 
 def test_default_config_is_the_reference_constants(pkg):

@@ -1,0 +1,116 @@
+"""First slice of the temperature modality: periodic-stripe segmentation, Code/temperature_sensor.py:437-540.
+
+Pins: the masks the reference itself stored for its five demo photographs (mask_{roi,roi_eff,sat,dark,light}.png under
+Multimodal_Sensor/Demos_report/<name>/temperature_sensing/).  tests/golden/temp_seg_report.json (tests/golden/make_temp_seg_report.py) holds the
+oracle-vs-stored pixel differences for all five; the FINAL_E masks are a committed fixture (tests/golden/temp_seg_FINAL_E.npz) next to the
+photograph (tests/golden/FINAL_E_deformed.jpg), so oracle and GPU path are checked against the reference's own output without the reference tree.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import align_oracle as A
+from oracle import temp_oracle as T
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _stored():
+    z = np.load(os.path.join(G, "temp_seg_FINAL_E.npz"))
+    shape = tuple(int(v) for v in z["shape"])
+    n = shape[0] * shape[1]
+    return tuple(int(v) for v in z["bbox"]), {k: np.unpackbits(z[k + "_bits"])[:n].reshape(shape).astype(bool) for k in ("roi", "roi_eff", "sat", "dark", "light")}
+
+
+def test_report_oracle_reproduces_all_stored_masks():
+    """all five demo photographs: every stored mask is reproduced pixel for pixel by the oracle"""
+    rows = json.load(open(os.path.join(G, "temp_seg_report.json")))
+    assert [r["name"] for r in rows] == ["FINAL_E_deformed", "FINAL_F_deformed", "FINAL_P_deformed", "FINAL_ROUND_METAL", "FINAL_TEMP_DEMO"]
+    for r in rows:
+        for k in ("roi", "roi_eff", "sat", "dark", "light"):
+            assert r["shape_equal_" + k] and r["diff_px_" + k] == 0, (r["name"], k)
+        assert (r["peak_x"], r["peak_y"]) == (1978, 1080) and r["chosen"] == "B_is_dark"
+        assert r["dark_pixels"] + r["light_pixels"] == r["roi_eff_pixels"] == r["stored_px_roi_eff"]
+
+
+def test_oracle_on_the_committed_photograph():
+    bbox, stored = _stored()
+    img = A.imread_bgr(os.path.join(G, "FINAL_E_deformed.jpg"))
+    cfg = T.TempSegConfig()
+    roi = T.roi_mask_from_circle(img.shape[0], img.shape[1], *cfg.outer_circle)
+    assert T.bbox_from_mask(roi, cfg.crop_pad_px) == bbox
+    dark, light, pack = T.segment_dark_light_gratings_periodic_fft(img, roi, cfg)
+    y0, y1, x0, x1 = bbox
+    got = {"roi": roi, "roi_eff": pack["roi_eff"], "sat": pack["sat"], "dark": dark, "light": light}
+    for k, v in got.items():
+        assert np.array_equal(v[y0:y1, x0:x1], stored[k]), k
+    assert abs(pack["dbg"]["carrier_period_px"] - 66.20689655172414) < 1e-12
+
+
+def _synthetic(h, w, seed, sat_blob=True):
+    """vertical stripes of period ~20 px with a slow illumination field, a warm tint and (optionally) a saturated blob"""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    s = 1.0 + 0.2 * np.cos(np.pi * np.hypot(xx - w / 2, yy - h / 2) / (0.7 * w))
+    g = 120.0 * s * (0.6 + 0.3 * np.sign(np.cos(2 * np.pi * (xx + 0.08 * yy) / 20.3))) + rng.normal(0, 3.0, (h, w))
+    if sat_blob:
+        g[(xx - 0.6 * w) ** 2 + (yy - 0.45 * h) ** 2 <= 30 ** 2] = 255.0
+    g = np.clip(g, 0, 255)
+    img = np.stack([0.9 * g, g, np.minimum(255.0, 1.05 * g)], axis=-1)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.gpu
+def test_gpu_segmentation_on_the_real_photograph(pkg):
+    """the HIP path on the reference's own 3840 x 2160 photograph: the reference's stored masks, pixel for pixel"""
+    bbox, stored = _stored()
+    img = A.imread_bgr(os.path.join(G, "FINAL_E_deformed.jpg"))
+    h, w = img.shape[:2]
+    roi = pkg.tempseg.roi_mask_from_circle(h, w, *pkg.tempseg.OUTER_CIRCLE)
+    assert pkg.tempseg.bbox_from_mask(roi, pkg.tempseg.CROP_PAD_PX) == bbox
+    dark, light, pack = pkg.segment_dark_light_gratings_periodic_fft(img, roi)
+    y0, y1, x0, x1 = bbox
+    got = {"roi": roi, "roi_eff": pack["roi_eff"], "sat": pack["sat"], "dark": dark, "light": light}
+    for k, v in got.items():
+        assert int((pkg.tempseg.crop2d(v, bbox) != stored[k]).sum()) == 0, k
+    d = pack["dbg"]
+    assert (d["peak_x"], d["peak_y"], d["chosen"]) == (1978, 1080, "B_is_dark")
+    assert d["dark_pixels"] + d["light_pixels"] == d["roi_eff_pixels"] == int(stored["roi_eff"].sum())
+    assert abs(d["carrier_period_px"] - 66.20689655172414) < 1e-12
+    rows = {r["name"]: r for r in json.load(open(os.path.join(G, "temp_seg_report.json")))}
+    assert abs(d["phi0_rad"] - rows["FINAL_E_deformed"]["phi0_rad"]) < 1e-6          # float32 mean of the normalised plane: ~1e-7 relative
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sat_blob", [True, False])
+def test_gpu_segmentation_against_oracle_synthetic(pkg, sat_blob):
+    """a smaller synthetic frame against the oracle, with a saturated blob (the stored photographs hold no saturated pixel, so their masks do
+    not exercise _make_saturation_mask's dilation) and without; masks may differ where |Re z| is at rounding level (the normalising mean is
+    a float32 pairwise sum upstream, a float64 sum here)"""
+    h, w = 512, 768
+    img = _synthetic(h, w, 5, sat_blob)
+    yy, xx = np.ogrid[:h, :w]
+    roi = (xx - 380) ** 2 + (yy - 250) ** 2 <= 230 ** 2
+    cfg_o = T.TempSegConfig()
+    dark_o, light_o, pack_o = T.segment_dark_light_gratings_periodic_fft(img, roi, cfg_o)
+    seg = pkg.TempSegmenter(h, w)
+    dark, light, pack = seg.segment(img, roi)
+    assert np.array_equal(pack["sat"], pack_o["sat"]) and np.array_equal(pack["roi_eff"], pack_o["roi_eff"])
+    assert bool(pack["sat"].any()) == sat_blob
+    assert pack["peak"] == tuple(int(v) for v in pack_o["peak"]) and pack["dbg"]["chosen"] == pack_o["dbg"]["chosen"]
+    assert abs(pack["dbg"]["phi0_rad"] - pack_o["dbg"]["phi0_rad"]) < 1e-5
+    assert int((dark != dark_o).sum()) <= 8 and int((light != light_o).sum()) <= 8
+    assert not (dark & light).any() and np.array_equal(dark | light, pack["roi_eff"])
+    for k in ("mean_gray_A", "mean_gray_B"):
+        assert abs(pack["dbg"][k] - pack_o["dbg"][k]) <= 1e-3 * pack_o["dbg"][k]
+    # error behaviour: an ROI that is saturated everywhere is refused as upstream does (:445-446)
+    if sat_blob:
+        tiny = (xx - 0.6 * w) ** 2 + (yy - 0.45 * h) ** 2 <= 10 ** 2
+        with pytest.raises(RuntimeError):
+            seg.segment(img, tiny)
+        with pytest.raises(RuntimeError):
+            T.segment_dark_light_gratings_periodic_fft(img, tiny, cfg_o)
+    with pytest.raises(ValueError):
+        seg.segment(img[:, :-1], roi[:, :-1])

@@ -27,6 +27,8 @@ EXPORTS = [
     "vistaf_depth_map_to_volume", "vistaf_predict_force_from_volume",
 ]
 TEST_EXPORTS = ["vistaf_ftp_test_set"]   # csrc/test_hooks.h: kernel tier selection / debug planes for the parity tests
+TEMP_EXPORTS = ["vistaf_tempseg_default_config", "vistaf_tempseg_create", "vistaf_tempseg_destroy", "vistaf_tempseg_segment"]   # include/vistaf_temp.h
+TEMPSEG_NINFO = 16
 ALIGN_EXPORTS = [            # include/vistaf_align.h
     "vistaf_align_default_config", "vistaf_align_create", "vistaf_align_destroy", "vistaf_align_geometry",
     "vistaf_align_set_reference", "vistaf_align_batch",
@@ -54,6 +56,12 @@ _DBL_FIELDS = [
 
 class CConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in _INT_FIELDS] + [(n, ctypes.c_double) for n in _DBL_FIELDS]
+
+
+class CTempSegConfig(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("seg_band_radius", "seg_dc_exclusion", "seg_illum_sigma", "sat_thresh_gray", "sat_dilate_ksize",
+                                                "post_close_kx", "post_close_ky", "post_open_kx", "post_open_ky", "n_peaks")] + \
+               [("seg_peak_max_dy_from_center", ctypes.c_double)]
 
 
 _lib = None
@@ -92,7 +100,12 @@ def load():
     lib.vistaf_depth_map_to_volume.argtypes = [vp, vp, ci, ci, ci, cd, cd, vp, vp]
     lib.vistaf_predict_force_from_volume.argtypes = [ctypes.POINTER(Curve), cd, ctypes.POINTER(cd)]
     lib.vistaf_ftp_test_set.argtypes = [vp, ctypes.c_char_p, ci]
-    for fn in EXPORTS + ALIGN_EXPORTS + TEST_EXPORTS:
+    lib.vistaf_tempseg_default_config.argtypes = [ctypes.POINTER(CTempSegConfig)]
+    lib.vistaf_tempseg_create.argtypes = [ctypes.POINTER(CTempSegConfig), ci, ci, ctypes.POINTER(vp)]
+    lib.vistaf_tempseg_destroy.argtypes = [vp]
+    lib.vistaf_tempseg_destroy.restype = None
+    lib.vistaf_tempseg_segment.argtypes = [vp, vp, vp, vp, vp, vp, vp, ctypes.POINTER(cd), vp]
+    for fn in EXPORTS + ALIGN_EXPORTS + TEST_EXPORTS + TEMP_EXPORTS:
         getattr(lib, fn)
     _lib = lib
     return lib

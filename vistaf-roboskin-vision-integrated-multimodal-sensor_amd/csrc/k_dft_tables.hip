@@ -48,6 +48,7 @@ __global__ void k_carrier_choose(const double *__restrict__ peaks_all, int npk, 
         pxf = (double)px + par(lg(py, px - 1), c0, lg(py, px + 1));
         pyf = (double)py + par(lg(py - 1, px), c0, lg(py + 1, px));
     }
+    g.px_raw = px; g.py_raw = py;
     g.peak_x = pxf; g.peak_y = pyf;
     g.kx = pxf - cxs; g.ky = pyf - cys;
     g.px_i = (int)rint(pxf); g.py_i = (int)rint(pyf);           // np.round: half to even
@@ -57,6 +58,7 @@ __global__ void k_carrier_choose(const double *__restrict__ peaks_all, int npk, 
     double dpx = pxf - g.px_i, dpy = pyf - g.py_i;
     if (!(fabs(dpx) > 1e-6 || fabs(dpy) > 1e-6)) { dpx = 0.0; dpy = 0.0; }
     g.dpx = dpx; g.dpy = dpy;
+    g.keep_carrier = 0;
     g.period = fabs(g.kx) > 1e-9 ? (double)Wf / fabs(g.kx) : 0.0;
     if (!isfinite(g.peak_x) || !isfinite(g.peak_y)) g.ok = 0;
     geom[b] = g;
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256) void k_build_tables(const CarrierGeom *__restr
         if (t >= pw * w) return;
         const int c = t / w, x = t - c * w;
         const long long X = x + pad;
-        const long long m = posmod((long long)(c - pw / 2) * X, Wf);
+        const long long m = posmod((long long)(g.keep_carrier ? g.x0 + c - cxs : c - pw / 2) * X, Wf);
         double s, co;
         sincospi(2.0 * (double)m / (double)Wf - 2.0 * g.dpx * ((double)X / (double)Wf), &s, &co);
         Gx_all[b * sx + t] = make_double2(co, s);
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(256) void k_build_tables(const CarrierGeom *__restr
         if (t >= h * ph) return;
         const int y = t / ph, a = t - y * ph;
         const long long Y = y + pad;
-        const long long m = posmod((long long)(a - ph / 2) * Y, Hf);
+        const long long m = posmod((long long)(g.keep_carrier ? g.y0 + a - cys : a - ph / 2) * Y, Hf);
         double s, co;
         sincospi(2.0 * (double)m / (double)Hf - 2.0 * g.dpy * ((double)Y / (double)Hf), &s, &co);
         const double scale = 1.0 / ((double)Hf * (double)Wf);

@@ -53,7 +53,9 @@ struct CarrierGeom {
     double period;              // Wf / |kx| (0: invalid)
     int x0, y0, ph, pw;         // patch origin and size in the shifted spectrum
     int px_i, py_i;
-    int ok, pad_;
+    int px_raw, py_raw;         // the chosen integer peak itself (before the sub-bin refinement)
+    int ok;
+    int keep_carrier;           // 0: the patch is re-centred at DC before the inverse transform (FTP, :945-948); 1: band-pass in place
 };
 // table strides are in elements per frame (0: one table for the whole batch)
 void launch_dft_forward(const float *iw, const float *mu, const double2 *Ex, const double2 *Ey, size_t tab_stride_x, size_t tab_stride_y,
