@@ -10,6 +10,7 @@
 //
 // Every pass walks the plane itself (z f32 + mask u8 = 5 B/px, coordinates from two LDS tables) with
 // SEL_U / FIT_U independent loads in flight per thread: the passes are bound by memory round trips, not bytes.
+#include <algorithm>
 #include <type_traits>
 #include "kernels.hpp"
 #include "select.hpp"
@@ -291,37 +292,45 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit(const float *__restric
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
-// Register-resident variant for planes of at most RP * 1024 pixels (every batched configuration: 224 x 224 -> RP = 49).  Thread t keeps
-// its pixels t, t + 1024, ... (NaN = not fitted) in RP VGPRs for the whole fit: the ~30 passes of an IRLS fit (normal equations, histogram
-// refinement, candidate collection of the exact medians) read registers and two LDS coordinate tables instead of walking a working copy of
-// the plane through the memory system (measured on the global variant: 5.3 GB of HBM traffic per batch of 256 for 0.35 GB of input and
-// output).  Per thread the samples are visited in the same order and the sums are reduced in the same order as in k_robust_polyfit:
-// coefficients, medians and the residual plane are the same bits.
+// Register-resident, column-owning variant for the batched frame sizes (w <= 1024, h / floor(1024 / w64) <= 64; 224 x 224: RP = 56).
+//
+// Thread t owns ONE image column x (threads run along x, padded to a multiple of 64 so that every wave lies inside one row group) and
+// the rows y = grp + groups * k, k < RP, of it; its samples stay in RP VGPRs for the whole fit (NaN = not fitted).  The ~35 passes of an
+// IRLS fit then cost neither memory traffic (the first variants walked a working copy of the plane: 5.3 GB of HBM traffic per batch of
+// 256 for 0.35 GB of input and output) nor coordinate arithmetic: with x fixed per thread and y uniform per wave,
+//     fit(x, y) = (c0 x + c2 + c3 x^2) + y (c1 + c4 x) + c5 y^2 = A_t + y B_t + C_y        -- one fma and one add per sample,
+// and the normal equations are accumulated as the 8 per-thread column sums  P_b = sum_k w^2 y^b (b = 0..4),  Q_b = sum_k w^2 z y^b
+// (b = 0..2) in float64, multiplied by the powers of x once per iteration and thread:  (A^T W^2 A)_ij = sum x^a y^b w^2  over the 15
+// monomials of degree <= 4, rhs_i likewise.  Same minimisation as the reference's lstsq on (A * w, z * w) (:1119-1121); float64 sums of
+// exact products instead of float32-rounded rows, i.e. closer to the exact solution than either LAPACK's float32 SVD or the first variant.
+// Medians are exact order statistics as before.  The residual plane is evaluated with eval_poly2d's own operation order (:1093-1097).
 template <int RP>
-__global__ __launch_bounds__(SEL_T) void k_robust_polyfit_reg(const float *__restrict__ z_all, const uint8_t *__restrict__ mask_all, int order,
+__global__ __launch_bounds__(SEL_T) void k_robust_polyfit_col(const float *__restrict__ z_all, const uint8_t *__restrict__ mask_all, int order,
                                                               int iters, float c, int min_count, int min_mask_count, float *__restrict__ coef_out,
-                                                              float *__restrict__ resid_all, int h, int w, uint32_t magic)
+                                                              float *__restrict__ resid_all, int h, int w, int cols_pad, int groups)
 {
     __shared__ SelShared sh;
-    __shared__ double s_part[16][27];
-    __shared__ double s_sum[27];
+    __shared__ double s_part[16][21];
+    __shared__ double s_sum[21];
     __shared__ float s_coef[6];
-    __shared__ float s_tab[FIT_TAB];
+    __shared__ float s_yn[FIT_TAB];
     const size_t b = blockIdx.x;
     const int P = h * w, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int nc = order >= 2 ? 6 : 3;
     const float *z = z_all + b * (size_t)P;
     const uint8_t *m = mask_all + b * (size_t)P;
     const float cxf = (float)((w - 1) / 2.0), cyf = (float)((h - 1) / 2.0);
-    for (int i = tid; i < w + h; i += SEL_T)
-        s_tab[i] = i < w ? __fdiv_rn(__fsub_rn((float)i, cxf), cxf) : __fdiv_rn(__fsub_rn((float)(i - w), cyf), cyf);
+    for (int i = tid; i < h; i += SEL_T) s_yn[i] = __fdiv_rn(__fsub_rn((float)i, cyf), cyf);
+    const int col = tid % cols_pad, grp = __builtin_amdgcn_readfirstlane(tid / cols_pad);   // uniform inside a wave (cols_pad % 64 == 0)
+    const bool owner = col < w && grp < groups;
+    const float xn = __fdiv_rn(__fsub_rn((float)col, cxf), cxf);
     const float qnan = __uint_as_float(0x7fc00000u);
-    // ---- load: the thread's pixels, the count of fitted / masked pixels and the range of z
+    // ---- load this thread's column samples; count fitted / masked pixels, range of z
     float zr[RP];
     uint32_t cnt0 = 0, cntm = 0;
     unsigned long long mn0 = ~0ull, mx0 = 0;
     {
-        constexpr int LU = 8;                       // loads in flight per thread
+        constexpr int LU = 8;
         uint8_t mk[LU];
 #pragma unroll
         for (int u0 = 0; u0 < RP; u0 += LU) {
@@ -329,9 +338,10 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit_reg(const float *__res
             for (int v = 0; v < LU; v++) {
                 const int u = u0 + v;
                 if (u < RP) {
-                    const int p = tid + u * SEL_T;
-                    zr[u] = p < P ? z[p] : qnan;
-                    mk[v] = p < P ? m[p] : (uint8_t)0;
+                    const int y = grp + groups * u;
+                    const bool in = owner && y < h;
+                    zr[u] = in ? z[(size_t)y * w + col] : qnan;
+                    mk[v] = in ? m[(size_t)y * w + col] : (uint8_t)0;
                 }
             }
 #pragma unroll
@@ -348,7 +358,7 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit_reg(const float *__res
         }
     }
     __syncthreads();
-    uint32_t n = block_sum<uint32_t>(cnt0, sh.wsum);
+    const uint32_t n = block_sum<uint32_t>(cnt0, sh.wsum);
     if (min_mask_count > 0) cntm = block_sum<uint32_t>(cntm, sh.wsum);
     mn0 = block_min_u64(mn0, sh.red64);
     mx0 = block_max_u64(mx0, sh.red64);
@@ -357,24 +367,27 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit_reg(const float *__res
     const float zmin = key2f(zkmin), zmax = key2f(zkmax);
     const bool do_fit = (int)n >= min_count && (min_mask_count <= 0 || (int)cntm >= min_mask_count);
 
-    FitCtx ctx;
-    ctx.z = nullptr; ctx.m = nullptr; ctx.tab = s_tab; ctx.use_tab = true; ctx.w = w; ctx.magic = magic; ctx.cxf = cxf; ctx.cyf = cyf;
-    ctx.order = order; ctx.med = 0.f; ctx.mode = 0;
-    for (int i = 0; i < 6; i++) ctx.coef[i] = 0.f;
-    // every valid sample of this thread, in ascending pixel order, as key = r or |r - med| (ctx.mode)
+    float coef[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float At = 0.f, Bt = 0.f;          // fit(x, y) = At + yn * Bt + c5 * yn^2 for this thread's column
+    float med = 0.f;
+    int mode = 0;                      // 0: key = r, 1: key = |r - med|
+    // residual of sample u (its row is uniform across the wave: the yn read is a broadcast).  g0: an opaque copy of the row group made at
+    // the start of every pass -- as loop invariants the RP row coordinates would be hoisted out of the IRLS loop and kept live next to
+    // the samples (hundreds of spills)
+    auto resid_of = [&](int g0, int u, float zz) -> float {
+        const float yn = s_yn[min(g0 + groups * u, h - 1)];
+        const float fit = __fadd_rn(fmaf(yn, Bt, At), __fmul_rn(coef[5], __fmul_rn(yn, yn)));
+        return __fsub_rn(zz, fit);
+    };
     auto each = [&](auto body) {
-        // The pixel coordinates are recomputed in every pass from an opaque copy of the thread index: as loop invariants the compiler would
-        // hoist all 2 * RP of them out of the IRLS loop, keep them live next to the samples and spill (~1000 scratch reloads per thread).
-        int t0 = tid;
-        asm volatile("" : "+v"(t0));
+        int g0 = grp;
+        asm volatile("" : "+s"(g0));
 #pragma unroll
         for (int u = 0; u < RP; u++) {
             const float zz = zr[u];
             if (finitef(zz)) {
-                float xn, yn;
-                ctx.coords(t0 + u * SEL_T, xn, yn);
-                float r = ctx.resid(zz, xn, yn);
-                if (ctx.mode) r = fabsf(__fsub_rn(r, ctx.med));
+                float r = resid_of(g0, u, zz);
+                if (mode) r = fabsf(__fsub_rn(r, med));
                 body(f2key(r));
             }
         }
@@ -382,110 +395,112 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit_reg(const float *__res
 
     float csig = 1.f;
     for (int it = 0; do_fit && it < iters; it++) {
-        // the 27 sums in two sweeps over the registers (14 + 13 double accumulators at a time: the samples and 27 doubles do not fit the
-        // 128 VGPRs of a 1024-thread workgroup); each sum still visits the samples in the same order
-        auto sweep = [&](auto half) {
-            constexpr int K0 = decltype(half)::value ? 14 : 0, K1 = decltype(half)::value ? 27 : 14;
-            double acc[K1 - K0];
+        // ---- column sums P_b = sum w^2 yn^b (b = 0..4), Q_b = sum w^2 z yn^b (b = 0..2), float64
+        double Pb[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, Qb[3] = {0.0, 0.0, 0.0};
+        const float inv_csig = __fdiv_rn(1.0f, csig);
+        int g0 = grp;
+        asm volatile("" : "+s"(g0));
 #pragma unroll
-            for (int i = 0; i < K1 - K0; i++) acc[i] = 0.0;
-            int t0 = tid;
-            asm volatile("" : "+v"(t0));
-#pragma unroll
-            for (int u = 0; u < RP; u++) {
-                const float zz = zr[u];
-                if (finitef(zz)) {
-                    float xn, yn;
-                    ctx.coords(t0 + u * SEL_T, xn, yn);
-                    float wt = 1.f;
-                    if (it > 0) {
-                        float uu = __fdiv_rn(ctx.resid(zz, xn, yn), csig);
-                        wt = __fdiv_rn(1.0f, __fadd_rn(1.0f, __fmul_rn(uu, uu)));
-                    }
-                    float a[6];
-                    a[0] = __fmul_rn(xn, wt); a[1] = __fmul_rn(yn, wt); a[2] = wt;
-                    a[3] = __fmul_rn(__fmul_rn(xn, xn), wt); a[4] = __fmul_rn(__fmul_rn(xn, yn), wt); a[5] = __fmul_rn(__fmul_rn(yn, yn), wt);
-                    const double zw = (double)__fmul_rn(zz, wt);
-                    int k = 0;
-#pragma unroll
-                    for (int i = 0; i < 6; i++) {
-#pragma unroll
-                        for (int j = i; j < 6; j++) { if (k >= K0 && k < K1) acc[k - K0] = fma((double)a[i], (double)a[j], acc[k - K0]); k++; }
-                    }
-#pragma unroll
-                    for (int i = 0; i < 6; i++) { if (21 + i >= K0 && 21 + i < K1) acc[21 + i - K0] = fma((double)a[i], zw, acc[21 + i - K0]); }
+        for (int u = 0; u < RP; u++) {
+            const float zz = zr[u];
+            if (finitef(zz)) {
+                float wt = 1.f;
+                if (it > 0) {
+                    const float uu = __fmul_rn(resid_of(g0, u, zz), inv_csig);
+                    wt = __fdiv_rn(1.0f, __fadd_rn(1.0f, __fmul_rn(uu, uu)));
                 }
+                const double yd = (double)s_yn[min(g0 + groups * u, h - 1)];
+                const double w2 = (double)wt * (double)wt;
+                const double t1 = w2 * yd, t2 = t1 * yd, t3 = t2 * yd, t4 = t3 * yd;
+                Pb[0] += w2; Pb[1] += t1; Pb[2] += t2; Pb[3] += t3; Pb[4] += t4;
+                const double zw = w2 * (double)zz;
+                Qb[0] += zw; Qb[1] = fma(zw, yd, Qb[1]); Qb[2] = fma(zw, yd * yd, Qb[2]);
             }
+        }
+        // the 15 monomial sums m[a][b] = sum x^a P_b (a + b <= 4) and the 6 right-hand sides, reduced over the workgroup
+        double v21[21];
+        {
+            const double x1 = (double)xn, x2 = x1 * x1, x3 = x2 * x1, x4 = x2 * x2;
+            const double xp[5] = {1.0, x1, x2, x3, x4};
+            int k = 0;
 #pragma unroll
-            for (int i = 0; i < K1 - K0; i++) {
-                double v = wave_sum(acc[i]);
-                if (lane == 0) s_part[wid][K0 + i] = v;
-            }
-        };
-        sweep(std::false_type{});
-        sweep(std::true_type{});
+            for (int bb = 0; bb <= 4; bb++)
+#pragma unroll
+                for (int aa = 0; aa + bb <= 4; aa++) v21[k++] = xp[aa] * Pb[bb];     // k = index of (a, b), b-major
+            v21[15] = x1 * Qb[0]; v21[16] = Qb[1]; v21[17] = Qb[0]; v21[18] = x2 * Qb[0]; v21[19] = x1 * Qb[1]; v21[20] = Qb[2];
+        }
+#pragma unroll
+        for (int i = 0; i < 21; i++) {
+            const double v = wave_sum(v21[i]);
+            if (lane == 0) s_part[wid][i] = v;
+        }
         __syncthreads();
-        if (tid < 27) {
+        if (tid < 21) {
             double v = 0.0;
             for (int k = 0; k < 16; k++) v += s_part[k][tid];
             s_sum[tid] = v;
         }
         __syncthreads();
         if (tid == 0) {
+            // monomial (a, b) -> index in v21: b-major with 5, 4, 3, 2, 1 entries
+            auto mono = [&](int a, int bb) -> double { const int base[5] = {0, 5, 9, 12, 14}; return s_sum[base[bb] + a]; };
+            const int ea[6] = {1, 0, 0, 2, 1, 0}, eb[6] = {0, 1, 0, 0, 1, 2};          // exponents of the basis [x, y, 1, x^2, xy, y^2]
             double A[6][6], rhs[6];
-            int k = 0;
 #pragma unroll
             for (int i = 0; i < 6; i++) {
 #pragma unroll
-                for (int j = i; j < 6; j++) { A[i][j] = s_sum[k]; A[j][i] = s_sum[k]; k++; }
+                for (int j = 0; j < 6; j++) A[i][j] = mono(ea[i] + ea[j], eb[i] + eb[j]);
+                rhs[i] = s_sum[15 + i];
             }
-#pragma unroll
-            for (int i = 0; i < 6; i++) rhs[i] = s_sum[21 + i];
             bool ok = nc == 6 ? chol_solve<6>(A, rhs) : chol_solve<3>(A, rhs);
 #pragma unroll
             for (int i = 0; i < 6; i++) s_coef[i] = (ok && i < nc) ? (float)rhs[i] : 0.f;
         }
         __syncthreads();
-        for (int i = 0; i < 6; i++) ctx.coef[i] = s_coef[i];
-        if (it == iters - 1) break;
+        for (int i = 0; i < 6; i++) coef[i] = s_coef[i];
+        At = fmaf(coef[3], __fmul_rn(xn, xn), fmaf(coef[0], xn, coef[2]));
+        Bt = fmaf(coef[4], xn, coef[1]);
+        if (it == iters - 1) break;   // the weights of the last iteration are never used upstream
+        // ---- sigma = 1.4826 * (median |r - median r| + 1e-6); the value ranges come from bounds on |fit| (|xn|, |yn| <= 1)
         uint32_t kmin, kmax;
-        ctx.mode = 0;
+        mode = 0;
         {
             float fb = 0.f;
-            for (int i = 0; i < 6; i++) fb += fabsf(ctx.coef[i]);
+            for (int i = 0; i < 6; i++) fb += fabsf(coef[i]);
             fb = fb * 1.0001f + 1e-30f;
             kmin = f2key(zmin - fb - 1e-6f * fabsf(zmin)); kmax = f2key(zmax + fb + 1e-6f * fabsf(zmax));
         }
         const float medr = block_median_each(each, sh, n, kmin, kmax);
         __syncthreads();
-        ctx.med = medr; ctx.mode = 1;
+        med = medr; mode = 1;
         {
             float hi1 = fabsf(__fsub_rn(key2f(kmax), medr)), hi2 = fabsf(__fsub_rn(key2f(kmin), medr));
             kmin = f2key(0.f); kmax = f2key(hi1 > hi2 ? hi1 : hi2);
         }
         float mad = block_median_each(each, sh, n, kmin, kmax);
         __syncthreads();
-        ctx.mode = 0;
+        mode = 0;
         mad = __fadd_rn(mad, 1e-6f);
         csig = __fmul_rn(c, __fmul_rn(1.4826f, mad));
     }
-    if (tid < 6) coef_out[b * 6 + tid] = do_fit ? ctx.coef[tid] : 0.f;
+    if (tid < 6) coef_out[b * 6 + tid] = do_fit ? coef[tid] : 0.f;
     // residual plane: z - fit over the WHOLE plane, unfitted pixels included (fit evaluated as eval_poly2d does, :1093-1097, :1132-1135)
     float *out = resid_all + b * (size_t)P;
-    for (int p = tid; p < P; p += SEL_T) {
-        const float zin = z[p];
-        float fit = 0.f;
-        if (do_fit) {
-            float xn, yn;
-            ctx.coords(p, xn, yn);
-            fit = __fadd_rn(__fadd_rn(__fmul_rn(ctx.coef[0], xn), __fmul_rn(ctx.coef[1], yn)), ctx.coef[2]);
-            if (order >= 2) {
-                fit = __fadd_rn(fit, __fmul_rn(__fmul_rn(ctx.coef[3], xn), xn));
-                fit = __fadd_rn(fit, __fmul_rn(__fmul_rn(ctx.coef[4], xn), yn));
-                fit = __fadd_rn(fit, __fmul_rn(__fmul_rn(ctx.coef[5], yn), yn));
+    if (owner) {
+        for (int y = grp; y < h; y += groups) {
+            const float zin = z[(size_t)y * w + col];
+            float fit = 0.f;
+            if (do_fit) {
+                const float yn = s_yn[y];
+                fit = __fadd_rn(__fadd_rn(__fmul_rn(coef[0], xn), __fmul_rn(coef[1], yn)), coef[2]);
+                if (order >= 2) {
+                    fit = __fadd_rn(fit, __fmul_rn(__fmul_rn(coef[3], xn), xn));
+                    fit = __fadd_rn(fit, __fmul_rn(__fmul_rn(coef[4], xn), yn));
+                    fit = __fadd_rn(fit, __fmul_rn(__fmul_rn(coef[5], yn), yn));
+                }
             }
+            out[(size_t)y * w + col] = __fsub_rn(zin, fit);
         }
-        out[p] = __fsub_rn(zin, fit);
     }
 }
 
@@ -495,14 +510,17 @@ void launch_robust_polyfit(const float *z, const uint8_t *mask, int order, int i
 {
     // i / w == umulhi(i, magic) for every i < h * w as long as h * w * w < 2^32
     const uint32_t magic = ((unsigned long long)h * w * w < 0x100000000ull) ? (uint32_t)(0x100000000ull / (unsigned)w) + 1u : 0u;
-    const int P = h * w, need = (P + SEL_T - 1) / SEL_T;
-    if (need <= 64 && w + h <= FIT_TAB && magic) {
-#define VF_FIT_REG(RPV) hipLaunchKernelGGL(k_robust_polyfit_reg<RPV>, dim3(B), dim3(SEL_T), 0, st, z, mask, order, iters, c, min_count, min_mask_count, coef_out, resid_out, h, w, magic)
-        if (need <= 16) VF_FIT_REG(16);
-        else if (need <= 32) VF_FIT_REG(32);
-        else if (need <= 49) VF_FIT_REG(49);
-        else VF_FIT_REG(64);
-#undef VF_FIT_REG
+    const int cols_pad = ((w + 63) / 64) * 64;
+    const int groups = cols_pad <= SEL_T ? std::min(SEL_T / cols_pad, h) : 0;
+    const int need = groups ? (h + groups - 1) / groups : 1 << 30;
+    if (need <= 64 && h <= FIT_TAB) {
+#define VF_FIT_COL(RPV) hipLaunchKernelGGL(k_robust_polyfit_col<RPV>, dim3(B), dim3(SEL_T), 0, st, z, mask, order, iters, c, min_count, min_mask_count, coef_out, resid_out, h, w, cols_pad, groups)
+        if (need <= 16) VF_FIT_COL(16);
+        else if (need <= 32) VF_FIT_COL(32);
+        else if (need <= 48) VF_FIT_COL(48);
+        else if (need <= 56) VF_FIT_COL(56);
+        else VF_FIT_COL(64);
+#undef VF_FIT_COL
         return;
     }
     hipLaunchKernelGGL(k_robust_polyfit, dim3(B), dim3(SEL_T), 0, st, z, mask, order, iters, c, min_count, min_mask_count, coef_out, resid_out, h, w, magic);

@@ -385,6 +385,11 @@ void telea_window_debug_dump(int B)
         if (hbuf[b][7] - hbuf[b][0] > hbuf[worst][7] - hbuf[worst][0]) worst = b;
         mean += (double)(hbuf[b][7] - hbuf[b][0]) / B;
     }
+    {
+        unsigned long long fd[8];
+        if (hipMemcpyFromSymbol(fd, HIP_SYMBOL(g_fill_dbg), sizeof(fd)) == hipSuccess)
+            printf("[telea fill dbg] frame 0 cycle sums over all calls so far: reads+solve %llu | terms %llu | ordered sums %llu | estimate %llu | push %llu\n", fd[0], fd[1], fd[2], fd[3], fd[4]);
+    }
     for (int b : {0, worst}) {
         unsigned long long *x = hbuf[b];
         printf("[telea window dbg] frame %d cycles: load %llu | ring %llu | p1 seeds %llu | p1 queue %llu | negate %llu | p2 seeds %llu | p2 queue %llu | "

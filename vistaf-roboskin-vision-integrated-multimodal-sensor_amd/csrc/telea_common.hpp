@@ -407,6 +407,15 @@ __device__ __attribute__((always_inline)) inline int telea_pop_outside4(const Te
     return m;
 }
 
+#ifdef VISTAF_DEBUG
+__device__ unsigned long long g_fill_dbg[8];          // cycle sums of the fill's phases (frame 0 only): diagnostics
+#define FSTAMP(k) do { if (blockIdx.x == 0 && lane == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); g_fill_dbg[k] += t_ - fstamp_; fstamp_ = t_; } } while (0)
+#define FSTART() unsigned long long fstamp_ = __builtin_amdgcn_s_memtime()
+#else
+#define FSTAMP(k) do { } while (0)
+#define FSTART() do { } while (0)
+#endif
+
 // Telea march (icvTeleaInpaintFMM): pop p, fill every 4-neighbour that is still INSIDE and push it.  Returns the number of
 // pixels filled.
 // NS > 0: the disc of the estimator window has NS <= 64 positions, one per lane (telea_march_consts), the case of every shipped
@@ -431,6 +440,7 @@ __device__ __attribute__((always_inline)) inline int telea_pop_march(const Telea
         const int pi = p + (qn == 0 ? -ww : qn == 1 ? -1 : qn == 2 ? ww : 1);
         nfill++;
         if constexpr (NS > 0) {
+            FSTART();
             // One estimator chunk (disc <= 64 positions), written as ONE basic block: on a lone wave a taken branch costs tens of cycles and a
             // dependent instruction ~9, so every LDS read is issued up front (the T word read at pi itself is the stale one, but
             // pi is INSIDE and never enters the sums), every condition is a per-lane select, and the quadrant solve (an f64 chain)
@@ -456,6 +466,7 @@ __device__ __attribute__((always_inline)) inline int telea_pop_march(const Telea
             float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sq), 0xB1, 0xf, 0xf, false)); sq = o < sq ? o : sq;
             o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sq), 0x4E, 0xf, 0xf, false)); sq = o < sq ? o : sq;
             const float tc = wn_lane_f(sq, 0);
+            FSTAMP(0);                     // LDS reads + quadrant solve
             if (lane == 0) t[pi] = tc;
             // (all alternatives are evaluated, then selected: nested conditional expressions would come back as branches)
             const float gx2 = __fmul_rn(__fsub_rn(tr, tl), 0.5f), gxr = __fsub_rn(tr, tc), gxl = __fsub_rn(tc, tl);
@@ -480,10 +491,14 @@ __device__ __attribute__((always_inline)) inline int telea_pop_march(const Telea
             const float aJy = use ? -__fmul_rn(wgt, __fmul_rn(giy, ry)) : z;
             const float aS = use ? wgt : z;
             float Ia = aIa, Jx = aJx, Jy = aJy, s = aS;
+            FSTAMP(1);                     // weights and terms
             wn_seq_sum4<NS>(Ia, Jx, Jy, s, 1.0e-20f, lane);
+            FSTAMP(2);                     // ordered sums
             const float val = telea_estimate(Ia, Jx, Jy, s);
             if (lane == 0) { im[pi] = val; f[pi] = (uint8_t)(W_HOLE | W_BAND); }
+            FSTAMP(3);                     // final estimate + stores
             push(tc, pi);
+            FSTAMP(4);                     // queue push
             continue;
         }
         // (flag, T) of pi's up / left / down / right neighbours on lanes 0..3, shared by all lanes
