@@ -59,6 +59,30 @@ def _cpu_worker(args):
     return done, busy
 
 
+def _usable_cores():
+    """cores this process may really use: the scheduler affinity capped by the cgroup CPU quota (a GPU box hands each job a share of the host)"""
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    cores = min(cores, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    cores = min(cores, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return max(1, cores)
+
+
 def cpu_baselines(n, constants, budget_s, pairs=False):
     """The oracle (NumPy + C restatement of the reference's path; kind "port") timed on this host BEFORE the GPU is initialised (the
     worker processes are forked): (a) single process, frames sequential, as the reference's only batch driver does
@@ -68,13 +92,9 @@ def cpu_baselines(n, constants, budget_s, pairs=False):
     what = "uncached (reference, deformed) pairs" if pairs else "frames, reference-frame demodulation cached and excluded"
     done, dt = _cpu_worker((n, constants, 0, 1, budget_s, pairs))
     one = {"value": done / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-           "sample": f"{done} synthetic {n}x{n} {what}; sequential, single process on 1 of {os.cpu_count()} host cores, {dt:.1f} s; "
+           "sample": f"{done} synthetic {n}x{n} {what}; sequential, single process on 1 of {_usable_cores()} usable host cores ({os.cpu_count()} on the host), {dt:.1f} s; "
                      f"figure rendering excluded"}
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = _usable_cores()
     with mp.get_context("fork").Pool(cores) as pool:
         res = pool.map(_cpu_worker, [(n, constants, k, cores, budget_s * 0.75, pairs) for k in range(cores)])
     tot = sum(r[0] / r[1] for r in res)

@@ -487,8 +487,12 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit_col(const float *__res
     // residual plane: z - fit over the WHOLE plane, unfitted pixels included (fit evaluated as eval_poly2d does, :1093-1097, :1132-1135)
     float *out = resid_all + b * (size_t)P;
     if (owner) {
-        for (int y = grp; y < h; y += groups) {
-            const float zin = z[(size_t)y * w + col];
+#pragma unroll
+        for (int u = 0; u < RP; u++) {
+            const int y = grp + groups * u;
+            if (y >= h) break;
+            // fitted pixels still sit in the registers; only the others (masked out or NaN) are read again
+            const float zin = finitef(zr[u]) ? zr[u] : z[(size_t)y * w + col];
             float fit = 0.f;
             if (do_fit) {
                 const float yn = s_yn[y];
