@@ -430,11 +430,11 @@ static int reference_search(vistaf_ftp_handle *hd, int nb, CarrierGeom *geom_dev
     if (hd->search_cap < nb) {
         int rc;
         if (!hd->Exf) {
-            if ((rc = dalloc(hd, &hd->Exf, (size_t)w * Wf)) || (rc = dalloc(hd, &hd->Eyf, (size_t)Hf * h))) return rc;
+            if ((rc = dalloc(hd, &hd->Exf, (size_t)w * (Wf / 2 + 1))) || (rc = dalloc(hd, &hd->Eyf, (size_t)Hf * h))) return rc;
             launch_build_full_tables(hd->Exf, hd->Eyf, h, w, pad, Hf, Wf, st);
         }
         // (a smaller earlier set stays owned by the handle until destroy; this only grows when pair mode follows session mode)
-        if ((rc = dalloc(hd, &hd->search_tmp, (size_t)nb * h * Wf)) || (rc = dalloc(hd, &hd->search_mag, (size_t)nb * Hf * Wf)) ||
+        if ((rc = dalloc(hd, &hd->search_tmp, (size_t)nb * h * (Wf / 2 + 1) + 64)) || (rc = dalloc(hd, &hd->search_mag, (size_t)nb * Hf * Wf)) ||
             (rc = dalloc(hd, &hd->search_peaks, (size_t)nb * 192)))
             return rc;
         hd->search_cap = nb;

@@ -151,9 +151,9 @@ void launch_dft_forward(const float *iw, const float *mu, const double2 *Ex, con
     const int rb_lds = (int)((60 * 1024) / ((size_t)DFT_RR * w * sizeof(float)));     // staged rows must fit the default dynamic LDS limit
     if (rb > rb_lds) rb = rb_lds;
     if (rb < 1) rb = 1;
-    if (h % 16 == 0) {      // matrix-core form: strips of 16 rows inside one frame (one table per strip)
+    if (h % 16 == 0 || tab_stride_x == 0) {      // matrix-core form: a strip of 16 rows must use ONE table (shared, or inside one frame)
         const int rows = B * h;
-        hipLaunchKernelGGL(k_dft_fwd1_mfma, dim3((rows / 16 + 3) / 4), dim3(256), 0, st, iw, mu, Ex, tab_stride_x, tmpT, h, w, pw, rows);
+        hipLaunchKernelGGL(k_dft_fwd1_mfma, dim3(((rows + 15) / 16 + 3) / 4), dim3(256), 0, st, iw, mu, Ex, tab_stride_x, tmpT, h, w, pw, rows);
     } else {
         dim3 g1((h + rb * DFT_RR - 1) / (rb * DFT_RR), B);
         hipLaunchKernelGGL(k_dft_fwd1, g1, dim3(256), (size_t)rb * DFT_RR * w * sizeof(float), st, iw, mu, Ex, tab_stride_x, tmpT, h, w, pw, rb);
@@ -180,60 +180,10 @@ __global__ void k_dft_inv1(const double2 *__restrict__ patch, int pstride, const
     Q[(b * (size_t)ph + a) * w + x] = make_double2(ar, ai);
 }
 
-// stage 4: field[b, y, x] = sum_a Gy[y, a] * Q[b, a, x]; amp = |field| (np.abs -> float32, :997).  A thread produces DFT_RY rows of one
-// column: every Q word it loads feeds DFT_RY outputs.  The Gy rows of the block sit in LDS.  With a reference field (cref != null: the
+// stage 4: field[b, y, x] = sum_a Gy[y, a] * Q[b, a, x]; amp = |field| (np.abs -> float32, :997); with a reference field (cref != null: the
 // deformed frames) the same thread goes on to the phase difference angle(cdef * conj(cref)) -> float32 (:1681-1689) and the amplitude
 // product amp_ref * amp_def (:742), so the float64 field never travels to memory unless `field` is given (reference frame, debug planes).
-constexpr int DFT_RY = 8;
-__global__ __launch_bounds__(256) void k_dft_inv2(const double2 *__restrict__ Q, const double2 *__restrict__ Gy_all, size_t gy_stride,
-                                                  double2 *__restrict__ field, float *__restrict__ amp, const double2 *__restrict__ cref_all,
-                                                  const float *__restrict__ amp_ref_all, size_t ref_stride, float *__restrict__ prod,
-                                                  float *__restrict__ wrapped, int h, int w, int ph)
-{
-    extern __shared__ double2 gy_lds[];                  // [DFT_RY][ph]
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y0 = blockIdx.y * DFT_RY;
-    const size_t b = blockIdx.z;
-    const double2 *Gy = Gy_all + b * gy_stride;
-    for (int i = threadIdx.x; i < DFT_RY * ph; i += blockDim.x) {
-        const int r = i / ph, a = i - r * ph;
-        gy_lds[i] = y0 + r < h ? Gy[(size_t)(y0 + r) * ph + a] : make_double2(0.0, 0.0);
-    }
-    __syncthreads();
-    if (x >= w) return;
-    const double2 *Qb = Q + b * (size_t)ph * w;
-    double ar[DFT_RY], ai[DFT_RY];
-#pragma unroll
-    for (int r = 0; r < DFT_RY; r++) { ar[r] = 0.0; ai[r] = 0.0; }
-    for (int a = 0; a < ph; a++) {
-        const double2 q = Qb[(size_t)a * w + x];
-#pragma unroll
-        for (int r = 0; r < DFT_RY; r++) {
-            const double2 g = gy_lds[r * ph + a];
-            cmac(ar[r], ai[r], g.x, g.y, q.x, q.y);
-        }
-    }
-    const double2 *cref = cref_all ? cref_all + b * ref_stride : nullptr;
-    const float *amp_ref = amp_ref_all ? amp_ref_all + b * ref_stride : nullptr;
-#pragma unroll
-    for (int r = 0; r < DFT_RY; r++) {
-        if (y0 + r >= h) break;
-        const size_t p = (size_t)(y0 + r) * w + x, i = b * (size_t)h * w + p;
-        if (field) field[i] = make_double2(ar[r], ai[r]);
-        const float am = (float)sqrt(fma(ar[r], ar[r], ai[r] * ai[r]));
-        amp[i] = am;
-        if (cref) {
-            const double2 c = cref[p];
-            // cdef * conj(cref) as NumPy multiplies complex128: (ar*cr - ai*(-ci)) + i(ar*(-ci) + ai*cr)
-            const double rr = ar[r] * c.x + ai[r] * c.y;
-            const double ri = ai[r] * c.x - ar[r] * c.y;
-            wrapped[i] = (float)atan2(ri, rr);
-            prod[i] = __fmul_rn(amp_ref[p], am);
-        }
-    }
-}
-
-// stage 4 on the matrix cores.  The complex product field = Gy . Q is the real float64 GEMM  [re | im] = [Gr | Gi] . [[Qr, Qi], [-Qi, Qr]]
+// On the matrix cores: the complex product field = Gy . Q is the real float64 GEMM  [re | im] = [Gr | Gi] . [[Qr, Qi], [-Qi, Qr]]
 // with K = 2 * ph: A[y][k] = Gr[y][k] for k < ph, Gi[y][k - ph] above; one double2 of Q per lane and k-step gives both B operands
 // ((q.x, q.y) below ph, (-q.y, q.x) above).  A wave owns 16 rows x 64 columns of one frame (four column tiles x {re, im} accumulators), a
 // workgroup four such strips; the epilogue is that of k_dft_inv2 (re and im of an element sit in the same lane and register index).
@@ -305,64 +255,148 @@ void launch_dft_inverse(const double2 *patch, int patch_stride, const double2 *G
 }
 
 // ---- full spectrum magnitude (reference-frame carrier search, shape_ftp.py:867-872), float64 as np.abs(fft2(float64)) ----
-__global__ void k_full1(const float *__restrict__ iw, const float *__restrict__ mu, const double2 *__restrict__ Ex, double2 *__restrict__ T,
-                        int h, int w, int Wf)
+// The frame is real, so F(-f) = conj F(f): only the columns fx = 0 .. Wf/2 are computed (stage 1 = k_dft_fwd1_mfma with the half table
+// as its "patch", stage 2 below) and every magnitude is written to its own and to its mirror position of the fftshift-ed plane.
+// Stage 2: mag[fy][fx] = | sum_y Eyf[fy][y] * T[y][fx] |, the complex product as the real float64 GEMM of k_dft_inv2_mfma (K = 2h); a wave
+// owns 16 frequency rows x 64 columns.
+__global__ __launch_bounds__(256) void k_full2_mfma(const double2 *__restrict__ T, const double2 *__restrict__ Eyf, double *__restrict__ mag_all,
+                                                    int h, int Hf, int Wf, int Wh)
 {
-    int fx = blockIdx.x * blockDim.x + threadIdx.x;
-    int y = blockIdx.y;
-    size_t b = blockIdx.z;
-    if (fx >= Wf) return;
-    const float *r = iw + b * (size_t)h * w + (size_t)y * w;
-    float m = mu[b];
-    double ar = 0.0, ai = 0.0;
-    for (int x = 0; x < w; x++) {
-        const double2 e = Ex[(size_t)x * Wf + fx];
-        const double v = __fsub_rn(r[x], m);
-        ar = fma(v, e.x, ar);
-        ai = fma(v, e.y, ai);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int x0 = blockIdx.x * 64, y0 = (blockIdx.y * 4 + wid) * 16;
+    const size_t b = blockIdx.z;
+    if (y0 >= Hf) return;
+    const int r = lane & 15, kk = lane >> 4;
+    const double *G = (const double *)Eyf;
+    const double2 *Tb = T + b * (size_t)h * Wh;
+    const int ya = min(y0 + r, Hf - 1);
+    v4f64 cre[4], cim[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) { cre[t] = (v4f64){0.0, 0.0, 0.0, 0.0}; cim[t] = (v4f64){0.0, 0.0, 0.0, 0.0}; }
+    const int K = 2 * h;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const int k = k0 + kk;
+        const bool in = k < K, hi = k >= h;
+        const int kq = in ? (hi ? k - h : k) : 0;
+        const double a = in ? G[((size_t)ya * h + kq) * 2 + (hi ? 1 : 0)] : 0.0;
+        double2 q[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) q[t] = Tb[(size_t)kq * Wh + min(x0 + 16 * t + r, Wh - 1)];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const double bre = in ? (hi ? -q[t].y : q[t].x) : 0.0, bim = in ? (hi ? q[t].x : q[t].y) : 0.0;
+            cre[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bre, cre[t], 0, 0, 0);
+            cim[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bim, cim[t], 0, 0, 0);
+        }
     }
-    T[(b * (size_t)h + y) * Wf + fx] = make_double2(ar, ai);
+    double *mag = mag_all + b * (size_t)Hf * Wf;
+    const int cy = Hf / 2, cx = Wf / 2;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int fx = x0 + 16 * t + r;
+        if (fx >= Wh) continue;
+#pragma unroll
+        for (int qd = 0; qd < 4; qd++) {
+            const int fy = y0 + kk + 4 * qd;
+            if (fy >= Hf) continue;
+            const double ar = cre[t][qd], ai = cim[t][qd];
+            const double m = sqrt(fma(ar, ar, ai * ai));
+            mag[(size_t)((fy + cy) % Hf) * Wf + (fx + cx) % Wf] = m;
+            const int mx = (Wf - fx) % Wf;                       // mirror column: outside the computed half unless fx is 0 or Wf/2
+            if (mx >= Wh) mag[(size_t)(((Hf - fy) % Hf + cy) % Hf) * Wf + (mx + cx) % Wf] = m;
+        }
+    }
 }
 
-// mag in fftshift layout
-__global__ void k_full2(const double2 *__restrict__ T, const double2 *__restrict__ Ey, double *__restrict__ mag, int h, int Hf, int Wf)
-{
-    int sx = blockIdx.x * blockDim.x + threadIdx.x;
-    int sy = blockIdx.y;
-    size_t b = blockIdx.z;
-    if (sx >= Wf) return;
-    int cy = Hf / 2, cx = Wf / 2;
-    int fy = (sy - cy + Hf) % Hf, fx = (sx - cx + Wf) % Wf;
-    const double2 *Tb = T + b * (size_t)h * Wf;
-    double ar = 0.0, ai = 0.0;
-    for (int y = 0; y < h; y++) {
-        const double2 e = Ey[(size_t)fy * h + y], v = Tb[(size_t)y * Wf + fx];
-        cmac(ar, ai, e.x, e.y, v.x, v.y);
-    }
-    mag[(b * (size_t)Hf + sy) * Wf + sx] = sqrt(fma(ar, ar, ai * ai));
-}
-
-void launch_dft_full_mag(const float *iw, const float *mu, const double2 *Ex_full, const double2 *Ey_full, double2 *tmp,
+// Ex_half: [w][Wh] (Wh = Wf/2 + 1), Ey_full: [Hf][h]; tmp: [B*h][Wh] double2
+void launch_dft_full_mag(const float *iw, const float *mu, const double2 *Ex_half, const double2 *Ey_full, double2 *tmp,
                          double *mag, int B, int h, int w, int Hf, int Wf, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_full1, dim3((Wf + 255) / 256, h, B), dim3(256), 0, st, iw, mu, Ex_full, tmp, h, w, Wf);
-    hipLaunchKernelGGL(k_full2, dim3((Wf + 255) / 256, Hf, B), dim3(256), 0, st, (const double2 *)tmp, Ey_full, mag, h, Hf, Wf);
+    const int Wh = Wf / 2 + 1, rows = B * h;
+    hipLaunchKernelGGL(k_dft_fwd1_mfma, dim3(((rows + 15) / 16 + 3) / 4), dim3(256), 0, st, iw, mu, Ex_half, (size_t)0, tmp, h, w, Wh, rows);
+    hipLaunchKernelGGL(k_full2_mfma, dim3((Wh + 63) / 64, (Hf + 63) / 64, B), dim3(256), 0, st, (const double2 *)tmp, Ey_full, mag, h, Hf, Wf, Wh);
 }
 
 // top-N magnitudes outside the DC box (find_top_peaks, shape_ftp.py:420-441), descending: out[b][3*i] = x, y, value.  One workgroup
-// per frame.  Magnitudes are non-negative doubles: their bit patterns order like the values.
+// per frame.  Magnitudes are non-negative doubles: their bit patterns order like the values.  ONE pass over the plane: every thread keeps
+// the TP_L largest of its strided elements (value bits, index) in registers; the N largest of the frame are then among the 1024 * TP_L
+// survivors unless one thread held more than TP_L of them -- detected (the thread's smallest kept value is then >= the N-th result) and
+// handled by the exact N-pass fallback.  Equal values: smaller linear index first.
+constexpr int TP_L = 4;
+__device__ inline bool tp_before(unsigned long long va, unsigned int ia, unsigned long long vb, unsigned int ib) { return va > vb || (va == vb && ia < ib); }
+
 __global__ __launch_bounds__(1024) void k_top_peaks(const double *__restrict__ mag_all, int Hf, int Wf, int dc, int npeaks, double *__restrict__ out_all)
 {
     __shared__ unsigned long long scratch[16];
     __shared__ unsigned int chosen[64];
+    __shared__ unsigned long long s_val[1024 * TP_L];
+    __shared__ unsigned int s_idx[1024 * TP_L];
+    __shared__ int s_overflow;
     const size_t n = (size_t)Hf * Wf;
     const double *mag = mag_all + blockIdx.x * n;
     double *out = out_all + blockIdx.x * (size_t)(3 * 64);
+    const int tid = threadIdx.x;
     int cy = Hf / 2, cx = Wf / 2;
     int y0 = max(0, cy - dc), y1 = min(Hf, cy + dc), x0 = max(0, cx - dc), x1 = min(Wf, cx + dc);
-    for (int k = 0; k < npeaks && k < 64; k++) {
+    if (npeaks > 64) npeaks = 64;
+    // ---- per-thread top TP_L (sorted, best first); `dropped` = the best element this thread had to discard
+    unsigned long long tv[TP_L], dropped_v = 0;
+    unsigned int ti[TP_L];
+    bool dropped = false;
+#pragma unroll
+    for (int k = 0; k < TP_L; k++) { tv[k] = 0ull; ti[k] = 0xffffffffu; }
+    for (size_t i = tid; i < n; i += 1024) {
+        const int y = (int)(i / Wf), x = (int)(i % Wf);
+        double v = mag[i];
+        if (y >= y0 && y < y1 && x >= x0 && x < x1) v = 0.0;
+        unsigned long long cv = (unsigned long long)__double_as_longlong(v);
+        unsigned int ci = (unsigned int)i;
+        if (!tp_before(cv, ci, tv[TP_L - 1], ti[TP_L - 1])) {       // not better than the worst kept: discard
+            if (!dropped || cv > dropped_v) dropped_v = cv;
+            dropped = true;
+            continue;
+        }
+        if (ti[TP_L - 1] != 0xffffffffu) { if (!dropped || tv[TP_L - 1] > dropped_v) dropped_v = tv[TP_L - 1]; dropped = true; }
+#pragma unroll
+        for (int k = 0; k < TP_L; k++) {                            // sorted insertion
+            if (tp_before(cv, ci, tv[k], ti[k])) { const unsigned long long xv = tv[k]; const unsigned int xi = ti[k]; tv[k] = cv; ti[k] = ci; cv = xv; ci = xi; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < TP_L; k++) { s_val[tid * TP_L + k] = tv[k]; s_idx[tid * TP_L + k] = ti[k]; }
+    if (tid == 0) s_overflow = 0;
+    __syncthreads();
+    // ---- N rounds of block-wide arg-max over the survivors
+    unsigned long long last_v = 0;
+    for (int k = 0; k < npeaks; k++) {
+        unsigned long long bv = 0;
+        unsigned int bi = 0xffffffffu;
+        for (int j = tid; j < 1024 * TP_L; j += 1024) {
+            const unsigned long long v = s_val[j];
+            const unsigned int ix = s_idx[j];
+            if (ix != 0xffffffffu && tp_before(v, ix, bv, bi)) { bv = v; bi = ix; }
+        }
+        const unsigned long long mv = block_max_u64(bv, scratch);
+        __syncthreads();
+        const unsigned long long mi = block_min_u64(bv == mv && bi != 0xffffffffu ? (unsigned long long)bi : ~0ull, scratch);
+        if (tid == 0) {
+            chosen[k] = (unsigned int)mi;
+            out[3 * k] = (double)((unsigned int)mi % Wf);
+            out[3 * k + 1] = (double)((unsigned int)mi / Wf);
+            out[3 * k + 2] = __longlong_as_double((long long)mv);
+        }
+        for (int j = tid; j < 1024 * TP_L; j += 1024)
+            if (s_idx[j] == (unsigned int)mi) s_idx[j] = 0xffffffffu;
+        last_v = mv;
+        __syncthreads();
+    }
+    // a discarded element that would have made the list: redo exactly (never seen on spectra: the peaks are few and far apart)
+    if (dropped && dropped_v >= last_v && last_v > 0) s_overflow = 1;
+    __syncthreads();
+    if (!s_overflow) return;
+    for (int k = 0; k < npeaks; k++) {
         unsigned long long best = 0;
-        for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
+        for (size_t i = tid; i < n; i += 1024) {
             int y = (int)(i / Wf), x = (int)(i % Wf);
             double v = mag[i];
             if (y >= y0 && y < y1 && x >= x0 && x < x1) v = 0.0;
@@ -374,9 +408,8 @@ __global__ __launch_bounds__(1024) void k_top_peaks(const double *__restrict__ m
         }
         best = block_max_u64(best, scratch);
         __syncthreads();
-        // smallest index among the (not yet chosen) elements holding that value
         unsigned long long idx = ~0ull;
-        for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
+        for (size_t i = tid; i < n; i += 1024) {
             int y = (int)(i / Wf), x = (int)(i % Wf);
             double v = mag[i];
             if (y >= y0 && y < y1 && x >= x0 && x < x1) v = 0.0;
@@ -385,7 +418,7 @@ __global__ __launch_bounds__(1024) void k_top_peaks(const double *__restrict__ m
             if (!skip && (unsigned long long)__double_as_longlong(v) == best && i < idx) idx = i;
         }
         idx = block_min_u64(idx, scratch);
-        if (threadIdx.x == 0) {
+        if (tid == 0) {
             chosen[k] = (unsigned int)idx;
             out[3 * k] = (double)(idx % Wf);
             out[3 * k + 1] = (double)(idx / Wf);

@@ -165,13 +165,15 @@ void launch_build_tables(const CarrierGeom *geom, int geom_stride, double2 *Ex, 
                        pad, Hf, Wf, pmax);
 }
 
-// Full-spectrum tables (carrier search): Exf[xs][f] (w x Wf), Eyf[f][ys] (Hf x h), frame independent.
+// Full-spectrum tables (carrier search): Exf[xs][f] (w x Wh, Wh = Wf/2 + 1: the spectrum of a real frame is Hermitian), Eyf[f][ys] (Hf x h),
+// frame independent.
 __global__ __launch_bounds__(256) void k_build_full_tables(double2 *__restrict__ Exf, double2 *__restrict__ Eyf, int h, int w, int pad, int Hf, int Wf)
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Wh = Wf / 2 + 1;
     if (blockIdx.y == 0) {
-        if (t >= (size_t)w * Wf) return;
-        const int xs = (int)(t / Wf), f = (int)(t - (size_t)xs * Wf);
+        if (t >= (size_t)w * Wh) return;
+        const int xs = (int)(t / Wh), f = (int)(t - (size_t)xs * Wh);
         double er = 0.0, ei = 0.0;
         foreach_reflection(xs, w, pad, Wf, [&](int X) { const double2 u = unit_root(((long long)f * X) % Wf, Wf, -1.0); er += u.x; ei += u.y; });
         Exf[t] = make_double2(er, ei);
