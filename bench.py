@@ -256,7 +256,8 @@ def main():
         # every sample carries its own reference frame (own noise realisation): [B, n, n, 3] fp16 next to the deformed frames
         refs_u8 = np.stack([pkg.synth._base(n, 0.0, np.random.default_rng(880000 + rank * B + b)) for b in range(B)])
         refs = torch.from_numpy(refs_u8).to(dev)[..., None].expand(-1, -1, -1, 3).to(torch.float16).contiguous()
-        sensors = [pkg.FtpSensor(None, pkg.synth.roi_circle(n), cfg, cal, neg, fm, max_batch=B, device=dev, frame_shape=(n, n))
+        # max_batch = 2 B: room for the reference and the deformed frames of a batch side by side, so both sets are preprocessed together
+        sensors = [pkg.FtpSensor(None, pkg.synth.roi_circle(n), cfg, cal, neg, fm, max_batch=2 * B, device=dev, frame_shape=(n, n))
                    for _ in range(max(1, args.inflight))]
         run = lambda s_, o_=None: s_.predict_pairs(refs, frames, o_)
     else:

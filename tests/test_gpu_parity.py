@@ -526,6 +526,13 @@ def test_uncached_pairs_128(pkg, cal):
         o1 = s1.predict_batch(defs[b][None])
         assert torch.equal(torch.nan_to_num(o1["height_map_mm"][0], nan=-7.0), torch.nan_to_num(out["height_map_mm"][b], nan=-7.0))
         assert torch.equal(o1["scalars"][0], out["scalars"][b])
+    # with room for both frame sets in the workspace (max_batch >= 2 B) the two preprocessing passes run as one: same bits
+    s2 = pkg.FtpSensor(None, pkg.synth.roi_circle(n), cfg, cal[0], cal[1], cal[2], max_batch=2 * nb, frame_shape=(n, n))
+    ob = s2.predict_pairs(refs, defs)
+    torch.cuda.synchronize()
+    assert torch.equal(ob["status"], out["status"]) and torch.equal(ob["scalars"], out["scalars"])
+    assert torch.equal(torch.nan_to_num(ob["height_map_mm"], nan=-7.0), torch.nan_to_num(out["height_map_mm"], nan=-7.0))
+    assert torch.equal(ob["output_reliable"], out["output_reliable"])
     # a featureless reference frame (its "carrier" is rounding noise) must not disturb its neighbours in the batch
     refs2, defs2 = refs[:4].copy(), defs[:4].copy()
     refs2[2] = 90

@@ -191,12 +191,16 @@ int upload_req(vistaf_ftp_handle *hd, float **d, const std::vector<float> &v)
 }
 
 // preprocessing shared by reference and deformed frames: frames -> iw (apodised, normalised) and mu
-void preprocess(vistaf_ftp_handle *hd, const void *frames, int format, int B, hipStream_t st, bool timed)
+// frames2 (pair mode, when the workspace holds 2 * nframes): a second set of nframes frames preprocessed in the SAME launches, as frames
+// [nframes, 2 * nframes) of every plane -- the one-wave-per-frame march then runs once over twice as many CUs instead of twice
+void preprocess(vistaf_ftp_handle *hd, const void *frames, int format, int nframes, hipStream_t st, bool timed, const void *frames2 = nullptr)
 {
     const vistaf_ftp_config &c = hd->cfg;
     int h = hd->h, w = hd->w, P = hd->P;
     if (timed) hipEventRecord(hd->ev[ST_GRAY_BAD], st);
-    launch_to_gray(frames, format, hd->img, B, P, st);
+    launch_to_gray(frames, format, hd->img, nframes, P, st);
+    if (frames2) launch_to_gray(frames2, format, hd->img + (size_t)nframes * P, nframes, P, st);
+    const int B = frames2 ? 2 * nframes : nframes;
     hipMemsetAsync(hd->bad_count, 0, sizeof(int) * B, st);
     if (c.bad_pixel_enable) {
         launch_sobel_mag(hd->img, hd->grad, B, h, w, st);
@@ -493,8 +497,9 @@ int vistaf_ftp_get_reference_info(const vistaf_ftp_handle *hd, double *o)
 // Everything after the demodulation (shape_ftp.py:1655-2037 + the force tail), shared by the session mode and the uncached-pair mode.
 // In: hd->amp-independent planes `prod` (amp_ref * amp_def) and `wrapped`.  pair_geom: per-frame carriers (pair mode) or null.
 static int post_demod(vistaf_ftp_handle *hd, int B, float *d_height_mm, uint8_t *d_reliable, double *d_scalars, int32_t *d_status,
-                      const CarrierGeom *pair_geom, hipStream_t st)
+                      const CarrierGeom *pair_geom, hipStream_t st, const int *bad_count = nullptr)
 {
+    if (!bad_count) bad_count = hd->bad_count;
     const vistaf_ftp_config &c = hd->cfg;
     int h = hd->h, w = hd->w, P = hd->P;
     bool timed = hd->timing;
@@ -636,7 +641,7 @@ static int post_demod(vistaf_ftp_handle *hd, int B, float *d_height_mm, uint8_t 
     pp.mm_per_px = hd->mm_per_px; pp.depth_eps_mm = c.depth_eps_mm; pp.period_px = hd->period; pp.force_curve = hd->fcurve;
     pp.pair_geom = pair_geom; pp.grating_pitch_mm = c.grating_pitch_mm;
     launch_tail(hd->depth, nullptr, hd->unitless, hd->roi, pp, hd->scalars, VISTAF_NSCALARS, nullptr, B, P, st);
-    launch_fill_scalars(hd->scalars, VISTAF_NSCALARS, hd->rel_count, hd->flipped, hd->amp_thr, hd->thr_used, hd->bg_med, hd->bad_count, B, st);
+    launch_fill_scalars(hd->scalars, VISTAF_NSCALARS, hd->rel_count, hd->flipped, hd->amp_thr, hd->thr_used, hd->bg_med, bad_count, B, st);
     launch_copy_out(hd->depth, orel, hd->status, d_height_mm, d_reliable, B, P, st);
     if (d_scalars) HIPCHK(hipMemcpyAsync(d_scalars, hd->scalars, sizeof(double) * VISTAF_NSCALARS * B, hipMemcpyDeviceToDevice, st));
     if (d_status) HIPCHK(hipMemcpyAsync(d_status, hd->status, sizeof(int32_t) * B, hipMemcpyDeviceToDevice, st));
@@ -704,22 +709,29 @@ int vistaf_ftp_predict_pairs(vistaf_ftp_handle *hd, const void *d_refs, const vo
     }
     HIPCHK(hipMemsetAsync(hd->status, 0, sizeof(int32_t) * B, st));
     const size_t sx = (size_t)w * pm, sy = (size_t)h * pm;
-    // ---- reference frames: preprocessing, carrier search, tables, demodulation
-    preprocess(hd, d_refs, format, B, st, false);
+    const bool together = 2 * B <= hd->maxB;      // room for both frame sets in the workspace: preprocess them in the same launches
+    const float *iw_def = hd->iw, *mu_def = hd->mu;
+    const int *bad_def = hd->bad_count;
+    if (together) {
+        HIPCHK(hipMemsetAsync(hd->status + B, 0, sizeof(int32_t) * B, st));
+        preprocess(hd, d_refs, format, B, st, timed, d_defs);
+        iw_def = hd->iw + (size_t)B * P; mu_def = hd->mu + B; bad_def = hd->bad_count + B;
+    } else preprocess(hd, d_refs, format, B, st, false);
+    // ---- reference frames: carrier search, tables, demodulation
     int rc = reference_search(hd, B, hd->pgeom, st);
     if (rc) return rc;
-    launch_pair_status(hd->pgeom, pm, hd->status, B, st);
+    launch_pair_status(hd->pgeom, pm, hd->status, together ? hd->status + B : nullptr, B, st);
     launch_build_tables(hd->pgeom, 1, hd->pEx, hd->pEy, hd->pGx, hd->pGy, sx, sy, B, h, w, pad, hd->Hf, hd->Wf, pm, st);
     launch_dft_forward(hd->iw, hd->mu, hd->pEx, hd->pEy, sx, sy, hd->win_full, hd->tmpT, hd->patch, pm * pm, B, h, w, pm, pm, st);
     launch_dft_inverse(hd->patch, pm * pm, hd->pGx, hd->pGy, sx, sy, hd->tmpT, hd->pcref, hd->pamp_ref, nullptr, nullptr, 0, nullptr, nullptr, B, h, w,
                        pm, pm, st);
     // ---- deformed frames, carrier locked to their own reference
-    preprocess(hd, d_defs, format, B, st, timed);
+    if (!together) preprocess(hd, d_defs, format, B, st, timed);
     if (timed) hipEventRecord(hd->ev[ST_DEMOD], st);
-    launch_dft_forward(hd->iw, hd->mu, hd->pEx, hd->pEy, sx, sy, hd->win_full, hd->tmpT, hd->patch, pm * pm, B, h, w, pm, pm, st);
+    launch_dft_forward(iw_def, mu_def, hd->pEx, hd->pEy, sx, sy, hd->win_full, hd->tmpT, hd->patch, pm * pm, B, h, w, pm, pm, st);
     launch_dft_inverse(hd->patch, pm * pm, hd->pGx, hd->pGy, sx, sy, hd->tmpT, hd->keep_planes ? hd->field : nullptr, hd->amp, hd->pcref, hd->pamp_ref,
                        (size_t)P, hd->prod, hd->wrapped, B, h, w, pm, pm, st);
-    return post_demod(hd, B, d_height_mm, d_reliable, d_scalars, d_status, hd->pgeom, st);
+    return post_demod(hd, B, d_height_mm, d_reliable, d_scalars, d_status, hd->pgeom, st, bad_def);
 }
 
 int vistaf_ftp_get_pair_info(vistaf_ftp_handle *hd, int batch, double *out /* [batch][VISTAF_NREFINFO] */, void *stream)

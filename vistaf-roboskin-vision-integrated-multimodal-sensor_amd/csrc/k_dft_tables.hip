@@ -70,16 +70,18 @@ void launch_carrier_choose(const double *peaks, int npk, const double *mag, int 
     hipLaunchKernelGGL(k_carrier_choose, dim3((B + 63) / 64), dim3(64), 0, st, peaks, npk, mag, Hf, Wf, bw, max_dy_frac, geom, B);
 }
 
-__global__ void k_pair_status(const CarrierGeom *__restrict__ geom, int pmax, int32_t *__restrict__ status, int B)
+// status2 (may be null): the status words of the pairs' deformed frames when both sets were preprocessed together: folded into status
+__global__ void k_pair_status(const CarrierGeom *__restrict__ geom, int pmax, int32_t *__restrict__ status, const int32_t *__restrict__ status2, int B)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const CarrierGeom g = geom[b];
+    if (status2 && status[b] == 0 && status2[b] != 0) status[b] = status2[b];
     if (!g.ok || g.ph != pmax || g.pw != pmax || !(g.period > 1e-12)) status[b] = 3;
 }
-void launch_pair_status(const CarrierGeom *geom, int pmax, int32_t *status, int B, hipStream_t st)
+void launch_pair_status(const CarrierGeom *geom, int pmax, int32_t *status, const int32_t *status2, int B, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_pair_status, dim3((B + 63) / 64), dim3(64), 0, st, geom, pmax, status, B);
+    hipLaunchKernelGGL(k_pair_status, dim3((B + 63) / 64), dim3(64), 0, st, geom, pmax, status, status2, B);
 }
 
 // exp(sign * 2*pi*i * m / N) for an exactly reduced 0 <= m < N

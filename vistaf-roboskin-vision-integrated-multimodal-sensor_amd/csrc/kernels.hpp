@@ -72,7 +72,7 @@ void launch_carrier_choose(const double *peaks, int npk, const double *mag, int 
 void launch_build_tables(const CarrierGeom *geom, int geom_stride, double2 *Ex, double2 *Ey, double2 *Gx, double2 *Gy, size_t stride_x,
                          size_t stride_y, int B, int h, int w, int pad, int Hf, int Wf, int pmax, hipStream_t st);
 // pair mode: frames without a usable carrier (or whose patch is clipped by the spectrum border) get status VISTAF_FRAME_NO_CARRIER
-void launch_pair_status(const CarrierGeom *geom, int pmax, int32_t *status, int B, hipStream_t st);
+void launch_pair_status(const CarrierGeom *geom, int pmax, int32_t *status, const int32_t *status2, int B, hipStream_t st);
 void launch_build_full_tables(double2 *Exf, double2 *Eyf, int h, int w, int pad, int Hf, int Wf, hipStream_t st);
 
 // ---- k_cc_dist.hip ----------------------------------------------------------------------------
