@@ -80,7 +80,7 @@ def _usable_cores():
             break
         except Exception:
             continue
-    return max(1, cores)
+    return max(1, min(cores, 64))          # (64 worker processes are plenty for a baseline figure; the GPU box allows few processes per job)
 
 
 def cpu_baselines(n, constants, budget_s, pairs=False):
