@@ -206,6 +206,8 @@ def main():
                     help="sessions (each with its own HIP stream and workspace) that take the steps in turn, so consecutive steps overlap on the GPU; "
                          "1 = strictly serial steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-tier", action="append", default=[], metavar="NAME=VALUE",
+                    help="diagnostic A/B runs: kernel tier hooks of csrc/test_hooks.h (e.g. telea_two_tier=0); the default run sets none")
     ap.add_argument("--cpu-budget-s", type=float, default=16.0)
     ap.add_argument("--pairs", action="store_true",
                     help="BASELINE configs[4] as SURVEY.md 8(d) restates it: uncached (reference, deformed) pairs, carrier search + reference "
@@ -263,6 +265,10 @@ def main():
     else:
         sensors = [pkg.FtpSensor(ref3, pkg.synth.roi_circle(n), cfg, cal, neg, fm, max_batch=B, device=dev) for _ in range(max(1, args.inflight))]
         run = lambda s_, o_=None: s_.predict_batch(frames, o_)
+    for kv in args.kernel_tier:
+        name, _, val = kv.partition("=")
+        for s_ in sensors:
+            s_._test_set(name, int(val))
     streams = [torch.cuda.Stream(device=dev) for _ in sensors] if len(sensors) > 1 else [None]
     sensor = sensors[0]
     outs = [run(s_) for s_ in sensors]

@@ -1,4 +1,4 @@
-/* vistaf_temp.h -- C ABI of the first slice of the temperature modality, part of libvistaf_ftp.so.
+/* vistaf_temp.h -- C ABI of the first two slices of the temperature modality, part of libvistaf_ftp.so.
  *
  * Replaces, on the MI355X, the periodic-stripe segmentation of the reference's temperature module -- the step that splits the
  * thermochromic grating of a full photograph into its dark and its light stripes before any regression runs:
@@ -61,6 +61,23 @@ void vistaf_tempseg_destroy(vistaf_tempseg_handle *h);
  * Errors as upstream: VISTAF_E_STATE when the ROI is empty after the saturation exclusion (:445-446).  Synchronises `stream`. */
 int vistaf_tempseg_segment(vistaf_tempseg_handle *h, const uint8_t *d_bgr, const uint8_t *d_roi, uint8_t *d_dark, uint8_t *d_light,
                            uint8_t *d_roi_eff, uint8_t *d_sat, double *info_host, void *stream);
+
+/* Second slice: the feature planes and the colour-support test the temperature models are evaluated on.
+ *
+ *   vistaf_temp_feature_planes   Code/temperature_sensor.py:278-293 `compute_feature_planes(image_bgr, blur_ksize)`:
+ *                                cv2.GaussianBlur(img, (5, 5), 0) on uint8 (fixed point, one rounding), cv2.cvtColor BGR2LAB on uint8 (integer
+ *                                table path) and BGR2GRAY, returned as the float32 planes "L", "a", "b", "gray" ([H,W], any may be NULL).
+ *                                blur_ksize: 5 (BLUR_KSIZE as shipped, :52) or <= 1 (no smoothing); other sizes are VISTAF_E_INVALID.
+ *   vistaf_temp_color_support    main() :793-799: chroma = sqrt((a - 128)^2 + (b - 128)^2) in float32 and
+ *                                color_support = dilate_bool_mask(light, dilate_ksize) & roi_eff & ~sat & (chroma >= chroma_min)
+ *                                (dilate_bool_mask :583-590, MORPH_ELLIPSE; defaults COLOR_CHROMA_MIN 10.0 :86, COLOR_SUPPORT_DILATE 3 :87;
+ *                                the threshold is compared in float32 like NumPy does for a Python scalar).  d_chroma / d_support may be NULL;
+ *                                the masks are only needed for d_support.
+ * Both are asynchronous on `stream`; the handle's frame size applies. */
+int vistaf_temp_feature_planes(vistaf_tempseg_handle *h, const uint8_t *d_bgr, int blur_ksize, float *d_L, float *d_a, float *d_b, float *d_gray,
+                               void *stream);
+int vistaf_temp_color_support(vistaf_tempseg_handle *h, const float *d_a, const float *d_b, const uint8_t *d_light, const uint8_t *d_roi_eff,
+                              const uint8_t *d_sat, double chroma_min, int dilate_ksize, float *d_chroma, uint8_t *d_support, void *stream);
 
 #ifdef __cplusplus
 }

@@ -5,7 +5,9 @@ TEST INFRASTRUCTURE ONLY (like everything under oracle/): the product never impo
 Follows Code/shape_ftp.py:1471-1537 (main: imread, BGR2GRAY, estimate_global_shift, warpAffine, ROI crop,
 align_crop_ecc) and the OpenCV 4.x routines those lines call, restated from their published algorithms:
 
-* cv2.cvtColor(BGR2GRAY) on uint8: fixed point, (R*4899 + G*9617 + B*1868 + 8192) >> 14;
+* cv2.cvtColor(BGR2GRAY) on uint8: fixed point with OpenCV 4.x's 15-bit coefficients, (B*3735 + G*19235 + R*9798 + 2^14) >> 15
+  (3.x used (R*4899 + G*9617 + B*1868 + 2^13) >> 14, which differs by one unit for 0.26 % of all colours; the reference pins no version --
+  the 4.x form is the one the path's own colour input uses, and on the five demo pairs it is the one closer to the stored bundles);
 * cv2.createHanningWindow: sqrt(hann_row * hann_col) in float32 (the implementation ends with cv::sqrt);
 * cv2.phaseCorrelate: windowed DFTs, unit-magnitude cross-power spectrum, inverse DFT, fftshift, arg-max,
   5x5 intensity-weighted centroid, shift = centre - centroid;
@@ -44,7 +46,7 @@ def bgr2gray_u8(bgr: np.ndarray) -> np.ndarray:
     b = bgr[..., 0].astype(np.int32)
     g = bgr[..., 1].astype(np.int32)
     r = bgr[..., 2].astype(np.int32)
-    return ((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14).astype(np.uint8)
+    return ((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15).astype(np.uint8)
 
 
 def hanning_window(h: int, w: int) -> np.ndarray:

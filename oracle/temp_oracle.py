@@ -10,6 +10,10 @@ dark and light stripes before any temperature regression runs:
   _make_saturation_mask                             :378-387
   _postprocess_mask                                 :390-406
   segment_dark_light_gratings_periodic_fft          :437-540
+  compute_feature_planes                            :278-293   (cv2.GaussianBlur on uint8 = OpenCV's fixed-point path; cv2.cvtColor BGR2LAB
+                                                                on uint8 = OpenCV's integer table path RGB2Lab_b; BGR2GRAY)
+  dilate_bool_mask                                  :583-590
+  chroma and the COLOR support mask of main()       :790-797
 
 NumPy calls are the reference's; OpenCV calls (cvtColor BGR2GRAY, GaussianBlur, getStructuringElement ELLIPSE / RECT, dilate, morphologyEx
 CLOSE / OPEN) go through oracle/cvlite.c / oracle/align_oracle.py like everywhere else in this oracle.  FFT precision follows
@@ -49,6 +53,9 @@ class TempSegConfig:
     post_open_kx: int = 3                 # :81
     post_open_ky: int = 7                 # :82
     n_peaks: int = 16                     # :457
+    blur_ksize: int = 5                   # :52  BLUR_KSIZE (feature smoothing)
+    color_chroma_min: float = 10.0        # :86  COLOR_CHROMA_MIN
+    color_support_dilate: int = 3         # :87  COLOR_SUPPORT_DILATE
 
 
 def circle_from_three_points(p1, p2, p3, eps: float = 1e-12):
@@ -190,3 +197,87 @@ def segment_dark_light_gratings_periodic_fft(image_bgr: np.ndarray, roi_full: np
     pack = {"dbg": dbg, "fft_mag": mag, "signal": s, "roi_eff": roi_eff, "sat": sat, "peak": (peak_x, peak_y), "angle_rad": dbg["carrier_angle_rad"],
             "period_px": dbg["carrier_period_px"], "raw_dark": raw_dark, "i_norm": i_norm, "z": z}
     return dark_final, light_final, pack
+
+
+# ---------------------------------------------------------------------------------------------
+# feature planes and colour support (second slice): temperature_sensor.py:278-293, :583-590, :790-797
+# ---------------------------------------------------------------------------------------------
+def gaussian_blur_u8_ksize5(img_u8: np.ndarray) -> np.ndarray:
+    """cv2.GaussianBlur(uint8 image, (5, 5), 0).  For 8-bit images OpenCV runs its fixed-point filter: the kernel of ksize 5 / sigma 0 is the
+    tabulated [1, 4, 6, 4, 1] / 16 (cv::getGaussianKernel's small_gaussian_tab), both passes are exact in 8.8 / 16.16 fixed point and the
+    ONE rounding at the end is (sum + 128) >> 8; BORDER_REFLECT_101."""
+    wts = np.array([1, 4, 6, 4, 1], np.int64)
+    img = img_u8 if img_u8.ndim == 3 else img_u8[..., None]
+    h, w = img.shape[:2]
+    p = np.pad(img.astype(np.int64), ((2, 2), (2, 2), (0, 0)), mode="reflect")
+    acc = np.zeros(img.shape, np.int64)
+    for i in range(5):
+        for j in range(5):
+            acc += wts[i] * wts[j] * p[i:i + h, j:j + w]
+    out = ((acc + 128) >> 8).astype(np.uint8)
+    return out if img_u8.ndim == 3 else out[..., 0]
+
+
+_LAB_SHIFT, _LAB_SHIFT2, _GAMMA_SHIFT = 12, 15, 3
+
+
+def lab_tables_u8():
+    """The integer tables of cv::RGB2Lab_b (color_lab.cpp): sRGB gamma (256 entries, scaled by 255 * 8), cube root (3072 entries, scaled by
+    2^15) and the sRGB -> XYZ (D65) matrix divided by the white point, scaled by 2^12."""
+    x = (np.arange(256, dtype=np.float32) / np.float32(255.0)).astype(np.float64)
+    g = np.where(x <= 0.04045, x / 12.92, ((x + 0.055) / 1.055) ** 2.4)
+    gtab = np.rint(255.0 * (1 << _GAMMA_SHIFT) * g).astype(np.int64)
+    n = 256 * 3 // 2 * (1 << _GAMMA_SHIFT)
+    xx = np.arange(n, dtype=np.float64) / (255.0 * (1 << _GAMMA_SHIFT))
+    f = np.where(xx < 0.008856, xx * 7.787 + 0.13793103448275862, np.cbrt(xx))
+    ctab = np.rint((1 << _LAB_SHIFT2) * f).astype(np.int64)
+    m = np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]])
+    wp = np.array([0.950456, 1.0, 1.088754])
+    coef = np.rint((1 << _LAB_SHIFT) * m / wp[:, None]).astype(np.int64)
+    return gtab, ctab, coef
+
+
+def bgr2lab_u8(img_bgr: np.ndarray):
+    """cv2.cvtColor(uint8 BGR, COLOR_BGR2LAB) -> (L, a, b) uint8 planes (8-bit Lab: L * 255 / 100, a + 128, b + 128)"""
+    gtab, ctab, c = lab_tables_u8()
+    b_, g_, r_ = gtab[img_bgr[..., 0]], gtab[img_bgr[..., 1]], gtab[img_bgr[..., 2]]
+
+    def desc(v, s):
+        return (v + (1 << (s - 1))) >> s
+    fx = ctab[desc(r_ * c[0, 0] + g_ * c[0, 1] + b_ * c[0, 2], _LAB_SHIFT)]
+    fy = ctab[desc(r_ * c[1, 0] + g_ * c[1, 1] + b_ * c[1, 2], _LAB_SHIFT)]
+    fz = ctab[desc(r_ * c[2, 0] + g_ * c[2, 1] + b_ * c[2, 2], _LAB_SHIFT)]
+    lscale = (116 * 255 + 50) // 100
+    lshift = -((16 * 255 * (1 << _LAB_SHIFT2) + 50) // 100)
+    L = desc(lscale * fy + lshift, _LAB_SHIFT2)
+    a = desc(500 * (fx - fy) + 128 * (1 << _LAB_SHIFT2), _LAB_SHIFT2)
+    b = desc(200 * (fy - fz) + 128 * (1 << _LAB_SHIFT2), _LAB_SHIFT2)
+    return tuple(np.clip(v, 0, 255).astype(np.uint8) for v in (L, a, b))
+
+
+def compute_feature_planes(image_bgr: np.ndarray, blur_ksize: int = 5) -> Dict[str, np.ndarray]:
+    """:278-293 (blur_ksize 5, the shipped BLUR_KSIZE, or <= 1 for none)"""
+    k = _ensure_odd(blur_ksize) if blur_ksize > 1 else 1
+    if k > 1:
+        if k != 5:
+            raise NotImplementedError("only the shipped BLUR_KSIZE = 5 is restated")
+        image_bgr = gaussian_blur_u8_ksize5(image_bgr)
+    L, a, b = bgr2lab_u8(image_bgr)
+    gray = A.bgr2gray_u8(image_bgr)
+    return {"L": L.astype(np.float32), "a": a.astype(np.float32), "b": b.astype(np.float32), "gray": gray.astype(np.float32)}
+
+
+def dilate_bool_mask(m: np.ndarray, k: int) -> np.ndarray:
+    """:583-590"""
+    k = _ensure_odd(int(k))
+    if k <= 1 or not np.any(m):
+        return m
+    return cv.dilate(m.astype(np.uint8) * 255, cv.ellipse_se(k), 1) > 127
+
+
+def color_support_mask(planes: Dict[str, np.ndarray], light_mask: np.ndarray, roi_eff: np.ndarray, sat: np.ndarray, cfg: TempSegConfig = TempSegConfig()):
+    """main() :790-797 -> (color_support, chroma)"""
+    a, b = planes["a"], planes["b"]
+    chroma = np.sqrt((a - 128.0) ** 2 + (b - 128.0) ** 2).astype(np.float32)
+    light_d = dilate_bool_mask(light_mask, cfg.color_support_dilate)
+    return light_d & roi_eff & (~sat) & (chroma >= float(cfg.color_chroma_min)), chroma

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Oracle vs the stripe-segmentation masks the reference stored for its five demo photographs.
 
-`Multimodal_Sensor/Demos_report/<name>/temperature_sensing/mask_{roi,roi_eff,sat,dark,light}.png` were written by
+`Multimodal_Sensor/Demos_report/<name>/temperature_sensing/mask_{roi,roi_eff,sat,dark,light,color_support}.png` and `debug_chroma_u8.png` were written by
 Code/temperature_sensor.py:803-812 (cropped to the outer-ROI bounding box + 10 px, :770) when Code/multimodal_sensor.py:495-499 ran the
 temperature module on `Final_demos_images/<name>.jpg`.  This script runs oracle/temp_oracle.py on the same photographs and writes
 tests/golden/temp_seg_report.json (per pair: differing pixels per mask, carrier peak, counts) and, for FINAL_E_deformed (whose photograph
@@ -36,7 +36,9 @@ def main():
         roi = T.roi_mask_from_circle(h, w, *cfg.outer_circle)
         y0, y1, x0, x1 = T.bbox_from_mask(roi, cfg.crop_pad_px)
         dark, light, pack = T.segment_dark_light_gratings_periodic_fft(img, roi, cfg)
-        got = {"roi": roi, "roi_eff": pack["roi_eff"], "sat": pack["sat"], "dark": dark, "light": light}
+        planes = T.compute_feature_planes(img, cfg.blur_ksize)
+        support, chroma = T.color_support_mask(planes, light, pack["roi_eff"], pack["sat"], cfg)
+        got = {"roi": roi, "roi_eff": pack["roi_eff"], "sat": pack["sat"], "dark": dark, "light": light, "color_support": support}
         d = f"{REF}/Multimodal_Sensor/Demos_report/{name}/temperature_sensing"
         stored = {k: np.asarray(Image.open(f"{d}/mask_{k}.png")) > 127 for k in got}
         row = {"name": name, "bbox": [y0, y1, x0, x1], "seconds": round(time.time() - t0, 1)}
@@ -47,6 +49,12 @@ def main():
             row["shape_equal_" + k] = bool(g.shape == stored[k].shape)
             row["diff_px_" + k] = int((g != stored[k]).sum()) if g.shape == stored[k].shape else -1
             row["stored_px_" + k] = int(stored[k].sum())
+        # debug_chroma_u8.png (:820-824): chroma scaled by its 99th percentile inside the ROI
+        ch = chroma.copy()
+        ch[~roi] = 0
+        ch_u8 = np.clip((ch / (np.nanpercentile(ch[roi], 99) + 1e-6)) * 255.0, 0, 255).astype(np.uint8)
+        st_ch = np.asarray(Image.open(f"{d}/debug_chroma_u8.png"))
+        row["diff_px_chroma_u8"] = int((ch_u8[y0:y1, x0:x1] != st_ch).sum())
         rows.append(row)
         print(json.dumps(row), flush=True)
         if name == "FINAL_E_deformed":

@@ -1,7 +1,8 @@
-"""First slice of the temperature modality: periodic-stripe segmentation, Code/temperature_sensor.py:437-540.
+"""First two slices of the temperature modality: periodic-stripe segmentation, Code/temperature_sensor.py:437-540, and the
+feature planes / colour-support test the temperature models are evaluated on (:278-293, :793-799).
 
-Pins: the masks the reference itself stored for its five demo photographs (mask_{roi,roi_eff,sat,dark,light}.png under
-Multimodal_Sensor/Demos_report/<name>/temperature_sensing/).  tests/golden/temp_seg_report.json (tests/golden/make_temp_seg_report.py) holds the
+Pins: the masks the reference itself stored for its five demo photographs (mask_{roi,roi_eff,sat,dark,light,color_support}.png and
+debug_chroma_u8.png under Multimodal_Sensor/Demos_report/<name>/temperature_sensing/).  tests/golden/temp_seg_report.json (tests/golden/make_temp_seg_report.py) holds the
 oracle-vs-stored pixel differences for all five; the FINAL_E masks are a committed fixture (tests/golden/temp_seg_FINAL_E.npz) next to the
 photograph (tests/golden/FINAL_E_deformed.jpg), so oracle and GPU path are checked against the reference's own output without the reference tree.
 """
@@ -21,7 +22,7 @@ def _stored():
     z = np.load(os.path.join(G, "temp_seg_FINAL_E.npz"))
     shape = tuple(int(v) for v in z["shape"])
     n = shape[0] * shape[1]
-    return tuple(int(v) for v in z["bbox"]), {k: np.unpackbits(z[k + "_bits"])[:n].reshape(shape).astype(bool) for k in ("roi", "roi_eff", "sat", "dark", "light")}
+    return tuple(int(v) for v in z["bbox"]), {k: np.unpackbits(z[k + "_bits"])[:n].reshape(shape).astype(bool) for k in ("roi", "roi_eff", "sat", "dark", "light", "color_support")}
 
 
 def test_report_oracle_reproduces_all_stored_masks():
@@ -29,8 +30,11 @@ def test_report_oracle_reproduces_all_stored_masks():
     rows = json.load(open(os.path.join(G, "temp_seg_report.json")))
     assert [r["name"] for r in rows] == ["FINAL_E_deformed", "FINAL_F_deformed", "FINAL_P_deformed", "FINAL_ROUND_METAL", "FINAL_TEMP_DEMO"]
     for r in rows:
-        for k in ("roi", "roi_eff", "sat", "dark", "light"):
+        for k in ("roi", "roi_eff", "sat", "dark", "light", "color_support"):
             assert r["shape_equal_" + k] and r["diff_px_" + k] == 0, (r["name"], k)
+        # debug_chroma_u8.png is chroma / p99 * 255 truncated to uint8: the restated 8-bit Lab tables are computed in double while OpenCV
+        # builds its own in float32 (softfloat), so single table entries may differ by one unit; measured <= 634 of ~2.07 M pixels
+        assert r["diff_px_chroma_u8"] <= 700, r["name"]
         assert (r["peak_x"], r["peak_y"]) == (1978, 1080) and r["chosen"] == "B_is_dark"
         assert r["dark_pixels"] + r["light_pixels"] == r["roi_eff_pixels"] == r["stored_px_roi_eff"]
 
@@ -43,10 +47,29 @@ def test_oracle_on_the_committed_photograph():
     assert T.bbox_from_mask(roi, cfg.crop_pad_px) == bbox
     dark, light, pack = T.segment_dark_light_gratings_periodic_fft(img, roi, cfg)
     y0, y1, x0, x1 = bbox
-    got = {"roi": roi, "roi_eff": pack["roi_eff"], "sat": pack["sat"], "dark": dark, "light": light}
+    planes = T.compute_feature_planes(img, cfg.blur_ksize)
+    support, chroma = T.color_support_mask(planes, light, pack["roi_eff"], pack["sat"], cfg)
+    got = {"roi": roi, "roi_eff": pack["roi_eff"], "sat": pack["sat"], "dark": dark, "light": light, "color_support": support}
     for k, v in got.items():
         assert np.array_equal(v[y0:y1, x0:x1], stored[k]), k
     assert abs(pack["dbg"]["carrier_period_px"] - 66.20689655172414) < 1e-12
+    assert chroma.dtype == np.float32 and all(p.dtype == np.float32 for p in planes.values())
+
+
+def test_oracle_lab_and_blur_known_answers():
+    """OpenCV's published 8-bit Lab values of the primaries / neutrals, and the algebra of the fixed-point 5 x 5 smoothing"""
+    px = np.array([[[255, 255, 255], [0, 0, 0], [0, 0, 255], [0, 255, 0], [255, 0, 0], [128, 128, 128]]], np.uint8)       # BGR
+    L, a, b = T.bgr2lab_u8(px)
+    assert np.stack([L, a, b], -1)[0].tolist() == [[255, 128, 128], [0, 128, 128], [136, 208, 195], [224, 42, 211], [82, 207, 20], [137, 128, 128]]
+    flat = np.full((9, 11, 3), 77, np.uint8)
+    assert np.array_equal(T.gaussian_blur_u8_ksize5(flat), flat)
+    imp = np.zeros((9, 9), np.uint8)
+    imp[4, 4] = 255
+    k = np.array([1, 4, 6, 4, 1], np.int64)
+    assert np.array_equal(T.gaussian_blur_u8_ksize5(imp)[2:7, 2:7], (np.outer(k, k) * 255 + 128) >> 8)
+    edge = np.zeros((6, 6), np.uint8)
+    edge[0, :] = 200                         # REFLECT_101: row -1 is row 1, row -2 is row 2 (both 0)
+    assert T.gaussian_blur_u8_ksize5(edge)[0, 3] == (200 * 6 * 16 + 128) >> 8
 
 
 def _synthetic(h, w, seed, sat_blob=True):
@@ -114,3 +137,51 @@ def test_gpu_segmentation_against_oracle_synthetic(pkg, sat_blob):
             T.segment_dark_light_gratings_periodic_fft(img, tiny, cfg_o)
     with pytest.raises(ValueError):
         seg.segment(img[:, :-1], roi[:, :-1])
+
+
+def _colour_frame(h, w, seed):
+    """smooth colour fields + noise so that chroma straddles the threshold and all of L, a, b vary"""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    chans = [127 + 100 * np.sin(xx / (17.0 + 9 * i) + i) * np.cos(yy / (23.0 - 5 * i)) + rng.normal(0, 12.0, (h, w)) for i in range(3)]
+    return np.clip(np.rint(np.stack(chans, -1)), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.gpu
+def test_gpu_feature_planes_and_colour_support_on_the_real_photograph(pkg):
+    """the HIP planes equal the oracle's bit for bit; the colour-support mask equals the one the reference stored, pixel for pixel"""
+    bbox, stored = _stored()
+    img = A.imread_bgr(os.path.join(G, "FINAL_E_deformed.jpg"))
+    h, w = img.shape[:2]
+    roi = pkg.tempseg.roi_mask_from_circle(h, w, *pkg.tempseg.OUTER_CIRCLE)
+    dark, light, pack = pkg.segment_dark_light_gratings_periodic_fft(img, roi)
+    planes = pkg.compute_feature_planes(img, pkg.tempseg.BLUR_KSIZE)
+    exp = T.compute_feature_planes(img, 5)
+    for k in ("L", "a", "b", "gray"):
+        assert planes[k].dtype == np.float32 and np.array_equal(planes[k], exp[k]), k
+    support, chroma = pkg.color_support_mask(planes, light, pack["roi_eff"], pack["sat"])
+    assert int((pkg.tempseg.crop2d(support, bbox) != stored["color_support"]).sum()) == 0
+    sup_o, chroma_o = T.color_support_mask(exp, light, pack["roi_eff"], pack["sat"])
+    assert np.array_equal(support, sup_o) and np.array_equal(chroma, chroma_o)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,blur,seed", [(144, 200, 5, 1), (64, 64, 5, 2), (160, 333, 1, 3), (80, 131, 5, 4)])
+def test_gpu_feature_planes_match_oracle_on_partial_tiles(pkg, h, w, blur, seed):
+    """frame widths that are no multiple of the 64 x 16 tile, with and without the smoothing; thresholds and dilation other than the defaults"""
+    img = _colour_frame(h, w, seed)
+    seg = pkg.TempSegmenter(h, w)
+    planes = seg.feature_planes(img, blur)
+    exp = T.compute_feature_planes(img, blur)
+    for k in ("L", "a", "b", "gray"):
+        assert np.array_equal(planes[k], exp[k]), k
+    rng = np.random.default_rng(seed)
+    light, roi_eff, sat = rng.random((h, w)) < 0.3, rng.random((h, w)) < 0.9, rng.random((h, w)) < 0.1
+    for cmin, kd in ((10.0, 3), (23.5, 5), (0.0, 1)):
+        cfg = T.TempSegConfig(color_chroma_min=cmin, color_support_dilate=kd)
+        sup, chroma = seg.color_support(planes, light, roi_eff, sat, cmin, kd)
+        sup_o, chroma_o = T.color_support_mask(exp, light, roi_eff, sat, cfg)
+        assert np.array_equal(chroma, chroma_o) and np.array_equal(sup, sup_o), (cmin, kd)
+    with pytest.raises(ValueError):
+        seg.feature_planes(img, 7)
+    seg.close()

@@ -14,11 +14,11 @@ from . import parallel
 from .align import FtpAligner, circle_from_3_points
 from . import calibrate
 from . import tempseg
-from .tempseg import TempSegConfig, TempSegmenter, segment_dark_light_gratings_periodic_fft
+from .tempseg import TempSegConfig, TempSegmenter, segment_dark_light_gratings_periodic_fft, compute_feature_planes, color_support_mask
 from .writers import (export_heightmap_files, height_map_bundle, multimodal_summary, result_record, temperature_statistics,
                       write_multimodal_summary, write_result_csv, write_result_json)
 
 __all__ = ["FtpConfig", "FtpSensor", "SCALAR_NAMES", "depth_map_to_volume_cm3", "estimate_mm_per_px", "load_calibration",
            "load_force_calibration", "predict", "predict_force_from_volume", "synth", "parallel", "FtpAligner", "circle_from_3_points", "calibrate", "_lib", "export_heightmap_files",
            "height_map_bundle", "result_record", "write_result_csv", "write_result_json", "multimodal_summary", "temperature_statistics",
-           "write_multimodal_summary", "tempseg", "TempSegConfig", "TempSegmenter", "segment_dark_light_gratings_periodic_fft"]
+           "write_multimodal_summary", "tempseg", "TempSegConfig", "TempSegmenter", "segment_dark_light_gratings_periodic_fft", "compute_feature_planes", "color_support_mask"]

@@ -27,7 +27,8 @@ EXPORTS = [
     "vistaf_depth_map_to_volume", "vistaf_predict_force_from_volume",
 ]
 TEST_EXPORTS = ["vistaf_ftp_test_set"]   # csrc/test_hooks.h: kernel tier selection / debug planes for the parity tests
-TEMP_EXPORTS = ["vistaf_tempseg_default_config", "vistaf_tempseg_create", "vistaf_tempseg_destroy", "vistaf_tempseg_segment"]   # include/vistaf_temp.h
+TEMP_EXPORTS = ["vistaf_tempseg_default_config", "vistaf_tempseg_create", "vistaf_tempseg_destroy", "vistaf_tempseg_segment",
+                "vistaf_temp_feature_planes", "vistaf_temp_color_support"]   # include/vistaf_temp.h
 TEMPSEG_NINFO = 16
 ALIGN_EXPORTS = [            # include/vistaf_align.h
     "vistaf_align_default_config", "vistaf_align_create", "vistaf_align_destroy", "vistaf_align_geometry",
@@ -105,6 +106,8 @@ def load():
     lib.vistaf_tempseg_destroy.argtypes = [vp]
     lib.vistaf_tempseg_destroy.restype = None
     lib.vistaf_tempseg_segment.argtypes = [vp, vp, vp, vp, vp, vp, vp, ctypes.POINTER(cd), vp]
+    lib.vistaf_temp_feature_planes.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp]
+    lib.vistaf_temp_color_support.argtypes = [vp, vp, vp, vp, vp, vp, cd, ci, vp, vp, vp]
     for fn in EXPORTS + ALIGN_EXPORTS + TEST_EXPORTS + TEMP_EXPORTS:
         getattr(lib, fn)
     _lib = lib

@@ -26,7 +26,8 @@ def _newer(target: str, deps) -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    hdrs = glob.glob(os.path.join(CSRC, "*.hpp")) + [os.path.join(HERE, "..", "include", "vistaf_ftp.h"), os.path.join(HERE, "..", "include", "vistaf_align.h")]
+    hdrs = glob.glob(os.path.join(CSRC, "*.hpp")) + [os.path.join(HERE, "..", "include", "vistaf_ftp.h"), os.path.join(HERE, "..", "include", "vistaf_align.h"),
+                                                     os.path.join(HERE, "..", "include", "vistaf_temp.h")]
     jobs = []
     objs = []
     for s in srcs:

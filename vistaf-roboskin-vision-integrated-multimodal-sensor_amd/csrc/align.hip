@@ -2,7 +2,7 @@
 // global shift, fixed-point warpAffine, ROI crop, ECC (euclidean) crop alignment.
 //
 // Arithmetic follows OpenCV 4.x (the test suite checks it against a CPU restatement of the same routines):
-//   * BGR2GRAY on uint8: (R*4899 + G*9617 + B*1868 + 8192) >> 14;
+//   * BGR2GRAY on uint8: OpenCV 4.x's 15-bit fixed point, (B*3735 + G*19235 + R*9798 + 2^14) >> 15 (the same form as k_to_gray);
 //   * phaseCorrelate: sqrt-Hanning window, R2C FFTs (hipFFT), unit-magnitude cross-power spectrum, inverse FFT, arg-max in
 //     fftshift order (first maximum in row-major order), 5x5 weighted centroid, shift = centre - centroid;
 //   * warpAffine INTER_LINEAR: source coordinates in AB_BITS = 10 fixed point, rounded to 1/32 pixel, uint8 through the
@@ -66,7 +66,7 @@ __global__ void k_bgr2gray(const uint8_t *__restrict__ bgr, uint8_t *__restrict_
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int b = bgr[3 * i], g = bgr[3 * i + 1], r = bgr[3 * i + 2];
-    int v = (r * 4899 + g * 9617 + b * 1868 + 8192) >> 14;
+    int v = (b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15;
     if (g8) g8[i] = (uint8_t)v;
     if (gf) gf[i] = (float)v;
 }

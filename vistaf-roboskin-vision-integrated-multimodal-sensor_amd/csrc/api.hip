@@ -228,7 +228,8 @@ void preprocess(vistaf_ftp_handle *hd, const void *frames, int format, int nfram
                 seq_mask = bad_big;
             }
             if (timed && mode != 2) { hipEventRecord(hd->ev[ST_INPAINT], st); ev_done = true; }
-            if (mode != 1) only = launch_inpaint_window(hd->img, seq_mask, range, hd->inpaint_win_scratch, B, h, w, st, (timed && !ev_done) ? hd->ev[ST_INPAINT] : nullptr);
+            if (mode != 1) only = launch_inpaint_window(hd->img, seq_mask, range, hd->inpaint_win_scratch, B, h, w, st, (timed && !ev_done) ? hd->ev[ST_INPAINT] : nullptr,
+                                                           hd->tiers.telea_two_tier != 0);
             launch_inpaint_telea(hd->img, seq_mask, range, hd->inpaint_scratch, hd->status, only, B, h, w, st);
         }
     } else if (timed) hipEventRecord(hd->ev[ST_INPAINT], st);
@@ -608,7 +609,7 @@ static int post_demod(vistaf_ftp_handle *hd, int B, float *d_height_mm, uint8_t 
         {
             const int range = std::min(100, std::max(1, cv_round((double)c.inpaint_radius)));
             const int32_t *only = nullptr;
-            if (hd->tiers.inpaint != 1) only = launch_inpaint_window(hd->z0, hd->hole_cand, range, hd->inpaint_win_scratch, B, h, w, st, nullptr);
+            if (hd->tiers.inpaint != 1) only = launch_inpaint_window(hd->z0, hd->hole_cand, range, hd->inpaint_win_scratch, B, h, w, st, nullptr, hd->tiers.telea_two_tier != 0);
             launch_inpaint_telea(hd->z0, hd->hole_cand, range, hd->inpaint_scratch, hd->status, only, B, h, w, st);
         }
         launch_hole_merge(hd->hmap, hd->reliable, hd->hole_cand, hd->z0, hd->out_rel, B, P, st);
@@ -784,6 +785,7 @@ int vistaf_ftp_test_set(vistaf_ftp_handle *hd, const char *name, int value)
     if (n == "inpaint_tier" && value >= 0 && value <= 2) hd->tiers.inpaint = value;
     else if (n == "flood_tier" && value >= 0 && value <= 2) hd->tiers.flood = value;
     else if (n == "chamfer_twopass") hd->tiers.chamfer_twopass = value != 0;
+    else if (n == "telea_two_tier") hd->tiers.telea_two_tier = value != 0;
     else if (n == "keep_planes") hd->keep_planes = value != 0;
     else return fail(VISTAF_E_INVALID, "unknown test hook or value: " + n);
     return 0;

@@ -49,7 +49,7 @@ __global__ void k_sobel_mag(const float *__restrict__ img, float *__restrict__ g
     float a20 = s[(size_t)yp * w + xm], a21 = s[(size_t)yp * w + x], a22 = s[(size_t)yp * w + xp];
     float gx = __fadd_rn(__fadd_rn(__fsub_rn(a02, a00), __fmul_rn(2.0f, __fsub_rn(a12, a10))), __fsub_rn(a22, a20));
     float gy = __fadd_rn(__fadd_rn(__fsub_rn(a20, a00), __fmul_rn(2.0f, __fsub_rn(a21, a01))), __fsub_rn(a22, a02));
-    grad[b * (size_t)h * w + (size_t)y * w + x] = __fsqrt_rn(__fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy)));
+    grad[b * (size_t)h * w + (size_t)y * w + x] = sqrtf(__fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy)));
 }
 
 void launch_sobel_mag(const float *img, float *grad, int B, int h, int w, hipStream_t st)

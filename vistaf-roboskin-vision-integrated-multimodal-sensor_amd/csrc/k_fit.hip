@@ -18,6 +18,7 @@
 namespace vf {
 
 constexpr int FIT_TAB = 4096;     // LDS coordinate tables: xn[w] followed by yn[h] when w + h <= FIT_TAB
+constexpr int FIT_YTAB = 1280;    // rows of the column variant's yn table (5 KB: the kernel stays at 44 KB of LDS, see k_inpaint_win.hip's first tier)
 constexpr int FIT_U = 8;          // samples per thread in flight in the normal-equation pass
 
 struct FitCtx {
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit_col(const float *__res
     __shared__ double s_part[16][21];
     __shared__ double s_sum[21];
     __shared__ float s_coef[6];
-    __shared__ float s_yn[FIT_TAB];
+    __shared__ float s_yn[FIT_YTAB];
     const size_t b = blockIdx.x;
     const int P = h * w, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int nc = order >= 2 ? 6 : 3;
@@ -517,7 +518,7 @@ void launch_robust_polyfit(const float *z, const uint8_t *mask, int order, int i
     const int cols_pad = ((w + 63) / 64) * 64;
     const int groups = cols_pad <= SEL_T ? std::min(SEL_T / cols_pad, h) : 0;
     const int need = groups ? (h + groups - 1) / groups : 1 << 30;
-    if (need <= 64 && h <= FIT_TAB) {
+    if (need <= 64 && h <= FIT_YTAB) {
 #define VF_FIT_COL(RPV) hipLaunchKernelGGL(k_robust_polyfit_col<RPV>, dim3(B), dim3(SEL_T), 0, st, z, mask, order, iters, c, min_count, min_mask_count, coef_out, resid_out, h, w, cols_pad, groups)
         if (need <= 16) VF_FIT_COL(16);
         else if (need <= 32) VF_FIT_COL(32);

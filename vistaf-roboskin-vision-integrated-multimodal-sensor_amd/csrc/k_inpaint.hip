@@ -280,7 +280,7 @@ __global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const
         int nidx = c2 * 64 + lane, sd = 2 * range + 1;
         float ry = (float)(range - nidx / sd), rx = (float)(range - nidx % sd);
         float len2 = __fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry));
-        pre_dstw[c2] = len2 > 0.f ? (float)(1. / (double)__fmul_rn(len2, __fsqrt_rn(len2))) : 0.f;
+        pre_dstw[c2] = len2 > 0.f ? (float)(1. / (double)__fmul_rn(len2, sqrtf(len2))) : 0.f;
     }
     const int side = 2 * range + 1, nn = side * side;
     for (int phase = 0; phase < 2; phase++) {
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const
                                 int lm = l - 1 + (l == 1), lp = l - 1 - (l == ec - 2);
                                 float ry = (float)(i - k), rx = (float)(j - l);
                                 float len2 = __fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry));
-                                float dstw = n0 == 0 ? pre_dstw[0] : (n0 == 64 ? pre_dstw[1] : (float)(1. / (double)__fmul_rn(len2, __fsqrt_rn(len2))));
+                                float dstw = n0 == 0 ? pre_dstw[0] : (n0 == 64 ? pre_dstw[1] : (float)(1. / (double)__fmul_rn(len2, sqrtf(len2))));
                                 float tk = (pk == pi) ? tc : ldc(t + pk);
                                 float lev = (float)(1. / (1 + fabs((double)__fsub_rn(tk, tc))));
                                 float dir = __fadd_rn(__fmul_rn(rx, gtx), __fmul_rn(ry, gty));

@@ -31,6 +31,12 @@ constexpr int WN_LOAD_U = 8;         // window cells per lane in flight while th
 constexpr int WN_RING_U = 6;         // inpaint ranges up to this have their ring taps unrolled (independent loads)
 constexpr int WN_QCAP = 4096;       // live queue entries (8 B each)
 constexpr int WN_CELLS = 14464;     // window cells (9 B each: T f32, image f32, flags u8)
+// First tier: 110.75 KB.  It leaves 49 KB of the CU's LDS to the kernels of the other sessions in flight (exact selection 37 KB, column
+// polyfit 44 KB, fused blur 26 KB ...), so a CU that marches a frame keeps working on another batch's stages instead of idling 3 SIMDs.
+// Frames whose window or queue does not fit are flagged and marched again by the full-size tier on a small grid.
+constexpr int WN1_CELLS = 10752;
+constexpr int WN1_QCAP = 2048;
+constexpr int WN2_GRID = 32;
 
 // diagnostic shader-clock stamps per frame: only in builds with -DVISTAF_DEBUG (see k_inpaint.hip)
 #ifdef VISTAF_DEBUG
@@ -310,23 +316,28 @@ __device__ inline bool wn_march(float *__restrict__ img, const uint8_t *__restri
     return true;
 }
 
+// retry == 0: block b marches frame b with the given capacities and flags fb[b] = 1 when its window or queue does not fit.
+// retry == 1: a small grid walks the batch and marches only the frames flagged by the previous tier (clearing the flag when it succeeds).
 __global__ __launch_bounds__(64) void k_telea_window(float *__restrict__ img_all, const uint8_t *__restrict__ bad_all,
-                                                     const int32_t *__restrict__ box, int32_t *__restrict__ fb, int range, int B, int h, int w)
+                                                     const int32_t *__restrict__ box, int32_t *__restrict__ fb, int range, int B, int h, int w,
+                                                     int cells_cap, int qcap, int retry)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char wn_lds[];
     const int lane = threadIdx.x;
-    const int b = blockIdx.x;
     const int P = h * w;
-    const int xmin = box[b], ymin = box[B + b], xmax = box[2 * B + b], ymax = box[3 * B + b];
-    if (xmin == 0x7f7f7f7f) return;                              // no hole pixel: nothing to inpaint
-    const int M = range + 1;
-    // window in padded frame coordinates [i0, i1] x [j0, j1], not clipped (cells beyond the image: BORDER)
-    const int i0 = ymin + 1 - M, i1 = ymax + 1 + M;
-    const int j0 = xmin + 1 - M, j1 = xmax + 1 + M;
-    const int wh = i1 - i0 + 1, ww = j1 - j0 + 1;
-    bool ok = wh * ww <= WN_CELLS;
-    if (ok) ok = wn_march<false>(img_all + (size_t)b * P, bad_all + (size_t)b * P, nullptr, 0, i0, j0, wh, ww, range, h, w, wn_lds, WN_CELLS, WN_QCAP, lane, b);
-    if (!ok && lane == 0) fb[b] = 1;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        if (retry && fb[b] != 1) continue;
+        const int xmin = box[b], ymin = box[B + b], xmax = box[2 * B + b], ymax = box[3 * B + b];
+        if (xmin == 0x7f7f7f7f) continue;                        // no hole pixel: nothing to inpaint
+        const int M = range + 1;
+        // window in padded frame coordinates [i0, i1] x [j0, j1], not clipped (cells beyond the image: BORDER)
+        const int i0 = ymin + 1 - M, i1 = ymax + 1 + M;
+        const int j0 = xmin + 1 - M, j1 = xmax + 1 + M;
+        const int wh = i1 - i0 + 1, ww = j1 - j0 + 1;
+        bool ok = wh * ww <= cells_cap;
+        if (ok) ok = wn_march<false>(img_all + (size_t)b * P, bad_all + (size_t)b * P, nullptr, 0, i0, j0, wh, ww, range, h, w, wn_lds, cells_cap, qcap, lane, b);
+        if (lane == 0) fb[b] = ok ? 0 : 1;
+    }
 }
 
 // Cluster front end: hole pixels farther apart than 2 * range + 3 never interact (rings and neighbourhoods reach
@@ -402,7 +413,8 @@ void telea_window_debug_dump(int B)
 size_t inpaint_win_scratch_bytes(int B) { return (size_t)B * 5 * sizeof(int32_t) + 256; }
 
 // box scratch: [4][B] bbox planes + [B] fallback flags.  Returns the device pointer of the fallback flags.
-int32_t *launch_inpaint_window(float *img, const uint8_t *bad, int range, void *scratch, int B, int h, int w, hipStream_t st, hipEvent_t ev_march)
+int32_t *launch_inpaint_window(float *img, const uint8_t *bad, int range, void *scratch, int B, int h, int w, hipStream_t st, hipEvent_t ev_march,
+                               bool two_tier)
 {
     int32_t *box = (int32_t *)scratch, *fb = box + 4 * (size_t)B;
     (void)hipMemsetAsync(box, 0x7f, (size_t)B * 8, st);
@@ -410,11 +422,16 @@ int32_t *launch_inpaint_window(float *img, const uint8_t *bad, int range, void *
     const int P = h * w;
     if (P % 16 == 0) hipLaunchKernelGGL(k_bad_bbox<true>, dim3((P / 16 + 255) / 256, B), dim3(256), 0, st, bad, box, B, h, w);
     else hipLaunchKernelGGL(k_bad_bbox<false>, dim3((P + 255) / 256, B), dim3(256), 0, st, bad, box, B, h, w);
-    const size_t lds = (size_t)WN_CELLS * 9 + (size_t)WN_QCAP * 8 + 256;
+    auto lds_bytes = [](int cells, int q) { return (size_t)cells * 9 + (size_t)q * 8 + 256; };
     static DynLdsOnce lds_once;
-        ensure_dyn_lds(lds_once, (const void *)k_telea_window, 160 * 1024);
+    ensure_dyn_lds(lds_once, (const void *)k_telea_window, 160 * 1024);
     if (ev_march) (void)hipEventRecord(ev_march, st);     // stage timing: the march starts here (the bbox pass belongs to the mask stage)
-    hipLaunchKernelGGL(k_telea_window, dim3(B), dim3(64), lds, st, img, bad, box, fb, range, B, h, w);
+    if (two_tier) {
+        hipLaunchKernelGGL(k_telea_window, dim3(B), dim3(64), lds_bytes(WN1_CELLS, WN1_QCAP), st, img, bad, box, fb, range, B, h, w, WN1_CELLS, WN1_QCAP, 0);
+        hipLaunchKernelGGL(k_telea_window, dim3(std::min(B, WN2_GRID)), dim3(64), lds_bytes(WN_CELLS, WN_QCAP), st, img, bad, box, fb, range, B, h, w,
+                           WN_CELLS, WN_QCAP, 1);
+    } else
+        hipLaunchKernelGGL(k_telea_window, dim3(B), dim3(64), lds_bytes(WN_CELLS, WN_QCAP), st, img, bad, box, fb, range, B, h, w, WN_CELLS, WN_QCAP, 0);
     return fb;
 }
 

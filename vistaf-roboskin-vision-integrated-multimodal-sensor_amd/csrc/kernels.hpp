@@ -13,6 +13,7 @@ struct Tiers {
     int inpaint = 2;            // 2: frame-window march (k_telea_window) + whole-frame fallback; 1: whole-frame kernel only; 0: cluster front end first
     int flood = 2;              // 2: batched pops (k_unwrap_flood_batch); 1: one pop per step (k_unwrap_flood_hot); 0: frontier scan
     int chamfer_twopass = 0;    // 1: force the one-wave two-pass chamfer even where the LDS closed form applies
+    int telea_two_tier = 1;     // 1: 111 KB first tier of the window march + full-size retry of the frames it hands back; 0: full size only
 };
 
 struct RowSpanSE {      // structuring element as per-row x spans (cv::getStructuringElement ELLIPSE)
@@ -95,7 +96,7 @@ void launch_inpaint_telea(float *img, const uint8_t *bad, int range, void *scrat
 // ---- k_inpaint_win.hip (LDS-resident window kernel; returns the per-frame fallback flags for launch_inpaint_telea)
 size_t inpaint_win_scratch_bytes(int B);
 int32_t *launch_inpaint_window(float *img, const uint8_t *bad, int range, void *scratch, int B, int h, int w, hipStream_t st,
-                               hipEvent_t ev_march = nullptr);
+                               hipEvent_t ev_march = nullptr, bool two_tier = true);
 
 // ---- k_inpaint_cl.hip (cluster-parallel front end; leaves oversized clusters in *bad_big_out) ----------
 size_t inpaint_cl_scratch_bytes_per_frame(int h, int w);
@@ -121,6 +122,14 @@ void launch_hole_candidates(const float *hmap, const uint8_t *reliable, const fl
 void launch_hole_tmp(const float *hmap, const uint8_t *reliable, const uint8_t *cand, const float *med, float *tmp, int B, int P, hipStream_t st);
 void launch_hole_zin(float *tmp_zin, const float *fill, int B, int P, hipStream_t st);
 void launch_hole_merge(float *hmap, const uint8_t *reliable, const uint8_t *cand, const float *zin, uint8_t *out_rel, int B, int P, hipStream_t st);
+
+// ---- k_lab.hip (temperature modality: feature planes and colour support, temperature_sensor.py:278-293, :790-799) --------------------
+constexpr int LAB_SHIFT = 12, LAB_SHIFT2 = 15, LAB_GAMMA_SHIFT = 3, LAB_CBRT_N = 256 * 3 / 2 * (1 << LAB_GAMMA_SHIFT);
+struct LabCoef { int c[9]; int lscale, lshift; };     // sRGB -> XYZ / white point in 2^12 fixed point, rows X, Y, Z, columns R, G, B
+void launch_feature_planes(const uint8_t *bgr, const uint16_t *gamma_tab, const uint16_t *cbrt_tab, const LabCoef &cf, bool blur, float *L, float *a,
+                           float *b, float *gray, int H, int W, hipStream_t st);
+void launch_color_support(const float *a, const float *b, const uint8_t *light_d, const uint8_t *roi_eff, const uint8_t *sat, float chroma_min,
+                          float *chroma, uint8_t *support, size_t n, hipStream_t st);
 
 // ---- k_post.hip -------------------------------------------------------------------------------
 struct PostParams {

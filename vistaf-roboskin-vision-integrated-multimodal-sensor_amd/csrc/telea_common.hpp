@@ -280,7 +280,7 @@ __device__ inline TeleaMarchConsts telea_march_consts(int lane, int ww, int rang
         float ry = (float)(-dk), rx = (float)(-dl);
         c.rx[c2] = rx; c.ry[c2] = ry;
         float len2 = __fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry));
-        c.dstw[c2] = len2 > 0.f ? (float)(1. / (double)__fmul_rn(len2, __fsqrt_rn(len2))) : 0.f;
+        c.dstw[c2] = len2 > 0.f ? (float)(1. / (double)__fmul_rn(len2, sqrtf(len2))) : 0.f;
     }
     c.d4 = (lane & 3) == 0 ? -ww : (lane & 3) == 1 ? -1 : (lane & 3) == 2 ? ww : 1;    // up, left, down, right
     return c;
@@ -538,7 +538,7 @@ __device__ __attribute__((always_inline)) inline int telea_pop_march(const Telea
                 on = nidx < nn && (dl * dl + dk * dk <= r2);
                 ry = (float)(-dk); rx = (float)(-dl);
                 float len2 = __fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry));
-                dstw = len2 > 0.f ? (float)(1. / (double)__fmul_rn(len2, __fsqrt_rn(len2))) : 0.f;
+                dstw = len2 > 0.f ? (float)(1. / (double)__fmul_rn(len2, sqrtf(len2))) : 0.f;
             }
             if (on) {
                 const int pk = pi + off;                      // inside the window: margin range+1

@@ -178,6 +178,8 @@ struct vistaf_tempseg_handle {
     int *cnt = nullptr;
     hipfftHandle plan = 0;
     bool have_plan = false;
+    uint16_t *gamma_tab = nullptr, *cbrt_tab = nullptr;       // cv::RGB2Lab_b tables
+    LabCoef lab;
 };
 
 namespace {
@@ -258,6 +260,29 @@ int vistaf_tempseg_create(const vistaf_tempseg_config *cfg, int H, int W, vistaf
         TRY(talloc(h, &h->gk, (size_t)n));
         if (hipMemcpy(h->gk, f.data(), n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { vistaf_tempseg_destroy(h); return set_error(VISTAF_E_HIP, "memcpy"); }
         h->gksize = n;
+    }
+    {
+        // The integer tables of OpenCV's 8-bit BGR2LAB: sRGB gamma of i / 255 scaled by 255 * 2^3, the Lab cube-root function of
+        // i / (255 * 2^3) scaled by 2^15, and the sRGB -> XYZ (D65) matrix over the white point scaled by 2^12.
+        std::vector<uint16_t> gt(256), ct(LAB_CBRT_N);
+        for (int i = 0; i < 256; i++) {
+            const double x = (double)((float)i / 255.0f);
+            const double g = x <= 0.04045 ? x / 12.92 : std::pow((x + 0.055) / 1.055, 2.4);
+            gt[i] = (uint16_t)std::nearbyint(255.0 * (1 << LAB_GAMMA_SHIFT) * g);
+        }
+        for (int i = 0; i < LAB_CBRT_N; i++) {
+            const double x = (double)i / (255.0 * (1 << LAB_GAMMA_SHIFT));
+            const double f = x < 0.008856 ? x * 7.787 + 0.13793103448275862 : std::cbrt(x);
+            ct[i] = (uint16_t)std::nearbyint((double)(1 << LAB_SHIFT2) * f);
+        }
+        const double m[9] = {0.412453, 0.357580, 0.180423, 0.212671, 0.715160, 0.072169, 0.019334, 0.119193, 0.950227};
+        const double wp[3] = {0.950456, 1.0, 1.088754};
+        for (int i = 0; i < 9; i++) h->lab.c[i] = (int)std::nearbyint((double)(1 << LAB_SHIFT) * m[i] / wp[i / 3]);
+        h->lab.lscale = (116 * 255 + 50) / 100;
+        h->lab.lshift = -((16 * 255 * (1 << LAB_SHIFT2) + 50) / 100);
+        TRY(talloc(h, &h->gamma_tab, (size_t)256)); TRY(talloc(h, &h->cbrt_tab, (size_t)LAB_CBRT_N));
+        if (hipMemcpy(h->gamma_tab, gt.data(), gt.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(h->cbrt_tab, ct.data(), ct.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { vistaf_tempseg_destroy(h); return set_error(VISTAF_E_HIP, "memcpy"); }
     }
     if (hipfftPlan2d(&h->plan, H, W, HIPFFT_R2C) != HIPFFT_SUCCESS) { vistaf_tempseg_destroy(h); return set_error(VISTAF_E_HIP, "hipfftPlan2d failed"); }
     h->have_plan = true;
@@ -359,6 +384,34 @@ int vistaf_tempseg_segment(vistaf_tempseg_handle *h, const uint8_t *d_bgr, const
         info[VISTAF_TS_CARRIER_ANGLE_RAD] = std::atan2(dy, dx);
         info[VISTAF_TS_CARRIER_PERIOD_PX] = fmag > 1e-9 ? 1.0 / fmag : std::nan("");
     }
+    return 0;
+}
+
+int vistaf_temp_feature_planes(vistaf_tempseg_handle *h, const uint8_t *d_bgr, int blur_ksize, float *d_L, float *d_a, float *d_b, float *d_gray,
+                               void *stream)
+{
+    if (!h || !d_bgr) return set_error(VISTAF_E_INVALID, "null argument");
+    const int k = blur_ksize > 1 ? ensure_odd(blur_ksize) : 1;
+    if (k != 1 && k != 5) return set_error(VISTAF_E_INVALID, "blur_ksize must be 5 (BLUR_KSIZE as shipped) or <= 1 (no smoothing)");
+    launch_feature_planes(d_bgr, h->gamma_tab, h->cbrt_tab, h->lab, k == 5, d_L, d_a, d_b, d_gray, h->H, h->W, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(VISTAF_E_HIP, std::string("launch: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int vistaf_temp_color_support(vistaf_tempseg_handle *h, const float *d_a, const float *d_b, const uint8_t *d_light, const uint8_t *d_roi_eff,
+                              const uint8_t *d_sat, double chroma_min, int dilate_ksize, float *d_chroma, uint8_t *d_support, void *stream)
+{
+    if (!h || !d_a || !d_b) return set_error(VISTAF_E_INVALID, "null argument");
+    if (d_support && (!d_light || !d_roi_eff || !d_sat)) return set_error(VISTAF_E_INVALID, "the support mask needs the light, roi_eff and sat masks");
+    hipStream_t st = (hipStream_t)stream;
+    const int k = ensure_odd(dilate_ksize);
+    if (k > 33) return set_error(VISTAF_E_INVALID, "structuring element taller than 33");
+    const uint8_t *light_d = d_light;
+    if (d_support && k > 1) { launch_morph(d_light, h->m1, 1, h->H, h->W, ellipse_se(k), true, nullptr, nullptr, st, h->prefix); light_d = h->m1; }
+    launch_color_support(d_a, d_b, light_d, d_roi_eff, d_sat, (float)chroma_min, d_chroma, d_support, h->P, st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(VISTAF_E_HIP, std::string("launch: ") + hipGetErrorString(e));
     return 0;
 }
 

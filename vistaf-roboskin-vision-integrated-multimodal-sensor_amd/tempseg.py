@@ -3,6 +3,8 @@
 Reference interface mirrored: Code/temperature_sensor.py
   * `segment_dark_light_gratings_periodic_fft(image_bgr, roi_full) -> (dark_final, light_final, pack)`  (:437-540)
   * `circle_from_three_points`, `roi_mask_from_circle`, `bbox_from_mask`, `crop2d`                        (:156-216)
+  * `compute_feature_planes(image_bgr, blur_ksize) -> {"L", "a", "b", "gray"}`                            (:278-293)
+  * the chroma / colour-support test of `main()` (with `dilate_bool_mask`, :583-590)                       (:793-799)
 backed by `vistaf_tempseg_*` of libvistaf_ftp.so (include/vistaf_temp.h).  PyTorch only holds the device buffers.  The temperature
 regressors (`TempModel.predict`, :236) are not part of this slice: their parameters only exist as pickled scikit-learn pipelines.
 """
@@ -42,6 +44,9 @@ class TempSegConfig:
 
 OUTER_CIRCLE = ((1845, 1818), (1517, 623), (2687, 914))       # temperature_sensor.py:37-39
 CROP_PAD_PX = 10                                              # :49
+BLUR_KSIZE = 5                                                # :52
+COLOR_CHROMA_MIN = 10.0                                       # :86
+COLOR_SUPPORT_DILATE = 3                                      # :87
 
 
 def circle_from_three_points(p1, p2, p3, eps: float = 1e-12) -> Tuple[float, float, float]:
@@ -140,16 +145,70 @@ class TempSegmenter:
         return dark, light, pack
 
 
+    # ---- second slice: feature planes and colour support -----------------------------------------------------------------------------
+    def _dev_u8(self, m, what):
+        t = m if torch.is_tensor(m) else torch.from_numpy(np.ascontiguousarray(np.asarray(m)).astype(np.uint8))
+        if tuple(t.shape) != (self.H, self.W):
+            raise ValueError(f"{what} mask shape does not match the frame")
+        return (t.to(self.device) != 0).to(torch.uint8).contiguous()
+
+    def feature_planes_device(self, image_bgr, blur_ksize: int = BLUR_KSIZE) -> Dict[str, torch.Tensor]:
+        """compute_feature_planes (:278-293) with the planes left on the device (float32 [H, W] tensors "L", "a", "b", "gray")"""
+        img = image_bgr if torch.is_tensor(image_bgr) else torch.from_numpy(np.ascontiguousarray(image_bgr))
+        if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3 or tuple(img.shape[:2]) != (self.H, self.W):
+            raise ValueError(f"image must be [{self.H},{self.W},3] uint8 (BGR)")
+        img = img.to(self.device).contiguous()
+        planes = {k: torch.empty((self.H, self.W), dtype=torch.float32, device=self.device) for k in ("L", "a", "b", "gray")}
+        stream = int(torch.cuda.current_stream(self.device).cuda_stream)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.vistaf_temp_feature_planes(self._h, img.data_ptr(), int(blur_ksize), planes["L"].data_ptr(), planes["a"].data_ptr(),
+                                                            planes["b"].data_ptr(), planes["gray"].data_ptr(), stream))
+        return planes
+
+    def feature_planes(self, image_bgr, blur_ksize: int = BLUR_KSIZE) -> Dict[str, np.ndarray]:
+        """Drop-in for temperature_sensor.compute_feature_planes(image_bgr, blur_ksize) (:278-293): float32 planes "L", "a", "b", "gray"."""
+        return {k: v.cpu().numpy() for k, v in self.feature_planes_device(image_bgr, blur_ksize).items()}
+
+    def color_support(self, planes, light_mask, roi_eff, sat, chroma_min: float = COLOR_CHROMA_MIN, dilate_ksize: int = COLOR_SUPPORT_DILATE):
+        """main() :793-799 -> (color_support bool [H, W], chroma float32 [H, W]); `planes` as returned by feature_planes[_device]"""
+        a, b = (p if torch.is_tensor(p) else torch.from_numpy(np.ascontiguousarray(p, dtype=np.float32)) for p in (planes["a"], planes["b"]))
+        a, b = a.to(self.device).contiguous(), b.to(self.device).contiguous()
+        if a.dtype != torch.float32 or b.dtype != torch.float32 or tuple(a.shape) != (self.H, self.W) or tuple(b.shape) != (self.H, self.W):
+            raise ValueError("planes must be float32 [H, W]")
+        light, roi_e, sat_m = self._dev_u8(light_mask, "light"), self._dev_u8(roi_eff, "roi_eff"), self._dev_u8(sat, "sat")
+        chroma = torch.empty((self.H, self.W), dtype=torch.float32, device=self.device)
+        support = torch.empty((self.H, self.W), dtype=torch.uint8, device=self.device)
+        stream = int(torch.cuda.current_stream(self.device).cuda_stream)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.vistaf_temp_color_support(self._h, a.data_ptr(), b.data_ptr(), light.data_ptr(), roi_e.data_ptr(), sat_m.data_ptr(),
+                                                           float(chroma_min), int(dilate_ksize), chroma.data_ptr(), support.data_ptr(), stream))
+        return support.cpu().numpy().astype(bool), chroma.cpu().numpy()
+
+
 _default: Optional[TempSegmenter] = None
 
 
-def segment_dark_light_gratings_periodic_fft(image_bgr, roi_full, config: Optional[TempSegConfig] = None):
-    """Drop-in for temperature_sensor.segment_dark_light_gratings_periodic_fft (:437): a session per frame size is built on first use."""
+def _session(h: int, w: int, cfg: Optional[TempSegConfig] = None) -> TempSegmenter:
     global _default
-    h, w = int(image_bgr.shape[0]), int(image_bgr.shape[1])
-    cfg = config or TempSegConfig()
+    cfg = cfg or (_default.config if _default is not None else TempSegConfig())
     if _default is None or (_default.H, _default.W) != (h, w) or _default.config != cfg:
         if _default is not None:
             _default.close()
         _default = TempSegmenter(h, w, cfg)
-    return _default.segment(image_bgr, roi_full)
+    return _default
+
+
+def compute_feature_planes(image_bgr, blur_ksize: int = 5) -> Dict[str, np.ndarray]:
+    """Drop-in for temperature_sensor.compute_feature_planes (:278)"""
+    return _session(int(image_bgr.shape[0]), int(image_bgr.shape[1])).feature_planes(image_bgr, blur_ksize)
+
+
+def color_support_mask(planes, light_mask, roi_eff, sat, chroma_min: float = 10.0, dilate_ksize: int = 3):
+    """The colour-support test of temperature_sensor.main() (:793-799) -> (color_support, chroma)"""
+    h, w = (int(v) for v in planes["a"].shape)
+    return _session(h, w).color_support(planes, light_mask, roi_eff, sat, chroma_min, dilate_ksize)
+
+
+def segment_dark_light_gratings_periodic_fft(image_bgr, roi_full, config: Optional[TempSegConfig] = None):
+    """Drop-in for temperature_sensor.segment_dark_light_gratings_periodic_fft (:437): a session per frame size is built on first use."""
+    return _session(int(image_bgr.shape[0]), int(image_bgr.shape[1]), config or TempSegConfig()).segment(image_bgr, roi_full)
