@@ -30,7 +30,8 @@ typedef struct vistaf_align_config {
     int32_t apply_global_shift;   /* APPLY_GLOBAL_SHIFT (shape_ftp.py:174), default 1 */
     int32_t use_ecc;              /* USE_ECC_CROP_ALIGNMENT (:176), default 1 */
     int32_t ecc_iters;            /* ECC_ITERS (:178), default 300 */
-    int32_t reserved;
+    int32_t gray_coeffs;          /* cv2.cvtColor(BGR2GRAY) fixed point: 0 = OpenCV 4.x, (B*3735 + G*19235 + R*9798 + 2^14) >> 15 (default);
+                                   * 1 = OpenCV 3.x, (R*4899 + G*9617 + B*1868 + 2^13) >> 14.  The reference pins no version */
     double ecc_eps;               /* ECC_EPS (:179), default 1e-7 */
     double ecc_gauss_sigma;       /* ECC_GAUSS_FILT (:180), default 5 */
     double shift_blur_sigma;      /* the sigma of estimate_global_shift (:530-531), 7 */

@@ -5,9 +5,12 @@ TEST INFRASTRUCTURE ONLY (like everything under oracle/): the product never impo
 Follows Code/shape_ftp.py:1471-1537 (main: imread, BGR2GRAY, estimate_global_shift, warpAffine, ROI crop,
 align_crop_ecc) and the OpenCV 4.x routines those lines call, restated from their published algorithms:
 
-* cv2.cvtColor(BGR2GRAY) on uint8: fixed point with OpenCV 4.x's 15-bit coefficients, (B*3735 + G*19235 + R*9798 + 2^14) >> 15
-  (3.x used (R*4899 + G*9617 + B*1868 + 2^13) >> 14, which differs by one unit for 0.26 % of all colours; the reference pins no version --
-  the 4.x form is the one the path's own colour input uses, and on the five demo pairs it is the one closer to the stored bundles);
+* cv2.cvtColor(BGR2GRAY) on uint8: fixed point.  OpenCV 4.x: (B*3735 + G*19235 + R*9798 + 2^14) >> 15; OpenCV 3.x:
+  (R*4899 + G*9617 + B*1868 + 2^13) >> 14 -- they differ by one unit for 0.26 % of all colours, and the reference pins no
+  version.  The stored outputs decide per data set: the 75 loading photographs and the five demo pairs (the force path) are
+  reproduced better by the 4.x form (median relative volume error 9.9e-5 against 1.7e-4; tests/golden/e2e_loading_report.json),
+  the four phase-to-height calibration photographs by the 3.x form (the 2 mm minimum to 2.6e-5 and its pixel exactly, against
+  2.5e-4 and one row off).  `generation` selects; 4 is the default and what the path's own colour input uses;
 * cv2.createHanningWindow: sqrt(hann_row * hann_col) in float32 (the implementation ends with cv::sqrt);
 * cv2.phaseCorrelate: windowed DFTs, unit-magnitude cross-power spectrum, inverse DFT, fftshift, arg-max,
   5x5 intensity-weighted centroid, shift = centre - centroid;
@@ -42,10 +45,13 @@ def imread_bgr(path: str) -> np.ndarray:
         return np.ascontiguousarray(np.asarray(im.convert("RGB"))[..., ::-1])
 
 
-def bgr2gray_u8(bgr: np.ndarray) -> np.ndarray:
+def bgr2gray_u8(bgr: np.ndarray, generation: int = 4) -> np.ndarray:
+    """generation 4: OpenCV 4.x's 15-bit coefficients (default); 3: OpenCV 3.x's 14-bit ones (module docstring)"""
     b = bgr[..., 0].astype(np.int32)
     g = bgr[..., 1].astype(np.int32)
     r = bgr[..., 2].astype(np.int32)
+    if int(generation) == 3:
+        return ((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14).astype(np.uint8)
     return ((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15).astype(np.uint8)
 
 
@@ -295,20 +301,20 @@ def align_crop_ecc(ref_u8: np.ndarray, mov_u8: np.ndarray, mask_bool: Optional[n
 
 
 def aligned_crops(reference_path: str, deformed_path: str, circle_pts, apply_global_shift=True, use_ecc=True,
-                  ecc_iters=300, ecc_eps=1e-7, ecc_gauss=5):
+                  ecc_iters=300, ecc_eps=1e-7, ecc_gauss=5, gray_generation: int = 4):
     """shape_ftp.main :1471-1537: returns (ref_gray crop u8, aligned deformed gray crop u8, (cx, cy, r) local, info)."""
     from . import ftp_oracle as O
     ref_bgr = imread_bgr(reference_path)
     def_bgr = imread_bgr(deformed_path)
     H, W = ref_bgr.shape[:2]
-    shift, response = estimate_global_shift(bgr2gray_u8(ref_bgr).astype(np.float32), bgr2gray_u8(def_bgr).astype(np.float32))
+    shift, response = estimate_global_shift(bgr2gray_u8(ref_bgr, gray_generation).astype(np.float32), bgr2gray_u8(def_bgr, gray_generation).astype(np.float32))
     if apply_global_shift:
         M = np.array([[1, 0, shift[0]], [0, 1, shift[1]]], np.float32)
         def_bgr = warp_affine(def_bgr, M, False, border="reflect")
     cx, cy, r = O.circle_from_3_points(*circle_pts)
     x1, x2, y1, y2 = max(0, cx - r), min(W, cx + r), max(0, cy - r), min(H, cy + r)
-    ref_gray = bgr2gray_u8(ref_bgr[y1:y2, x1:x2])
-    def_gray = bgr2gray_u8(def_bgr[y1:y2, x1:x2])
+    ref_gray = bgr2gray_u8(ref_bgr[y1:y2, x1:x2], gray_generation)
+    def_gray = bgr2gray_u8(def_bgr[y1:y2, x1:x2], gray_generation)
     h, w = ref_gray.shape
     cxl, cyl = cx - x1, cy - y1
     rl = int(min(r, cxl, cyl, w - 1 - cxl, h - 1 - cyl))

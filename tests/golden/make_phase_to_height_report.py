@@ -25,6 +25,7 @@ from oracle import ftp_oracle as O            # noqa: E402
 
 REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
 CIRCLE_PTS = ((1873, 1703), (1599, 707), (2575, 950))      # phase_to_height.py uses the same three ROI points as shape_ftp.py:41-43
+GRAY_GENERATION = int(os.environ.get("VISTAF_GRAY_GENERATION", "3"))   # this data set is reproduced best by OpenCV 3.x's BGR2GRAY (oracle/align_oracle.py)
 
 
 def main():
@@ -37,12 +38,12 @@ def main():
     out = []
     for row in rows:
         t0 = time.time()
-        rg, dg, (cx, cy, r), info = A.aligned_crops(f"{REF}/Final_demos_images/FINAL_reference.jpg", f"{REF}/Force/Phase_to_height/{row['file']}", CIRCLE_PTS)
+        rg, dg, (cx, cy, r), info = A.aligned_crops(f"{REF}/Final_demos_images/FINAL_reference.jpg", f"{REF}/Force/Phase_to_height/{row['file']}", CIRCLE_PTS, gray_generation=GRAY_GENERATION)
         rs = O.make_reference_state(rg, cx, cy, r, cfg)
         res = O.process_frame(dg, rs, cfg, cal, neg, None)
         v, (x, y) = res["argmin_unitless"]
         rec = {"file": row["file"], "stored_min": float(row["min_height_unitless"]), "stored_xy": [int(row["min_x"]), int(row["min_y"])],
-               "min": float(v), "xy": [int(x), int(y)], "ecc_iters": info["ecc_iters"], "s": round(time.time() - t0, 1)}
+               "min": float(v), "xy": [int(x), int(y)], "ecc_iters": info["ecc_iters"], "gray_generation": GRAY_GENERATION, "s": round(time.time() - t0, 1)}
         out.append(rec)
         print(json.dumps(rec), flush=True)
     json.dump(out, open(os.path.join(ROOT, "tests", "golden", "e2e_phase_to_height_report.json"), "w"), indent=1)

@@ -124,12 +124,13 @@ def test_phase_to_height_batch_job_driver(pkg, photos):
     Code/phase_to_height.py -> row of calibration_results.csv) on the reference's own calibration photograph
     `Force/Phase_to_height/Height_2mm_deformed.jpg` (tests/golden, a data file).  Expected: the stored row of the reference's
     calibration_results.csv (tests/golden/ref_phase_to_height_results.csv): min_height_unitless -1.26027 at (722, 588); the CPU
-    oracle gives -1.25980 at (722, 589) (tests/golden/e2e_phase_to_height_report.json).  Tolerance: 1e-3 unitless (0.08 %), one
-    pixel on the location -- the same bar the oracle meets against the stored row."""
+    oracle gives -1.26025 at (722, 588) with OpenCV 3.x's BGR2GRAY coefficients -- the generation that reproduces this data set
+    (oracle/align_oracle.py; `gray_coeffs = 1` of vistaf_align_config) -- tests/golden/e2e_phase_to_height_report.json.
+    Tolerance: 5e-4 unitless (0.04 %) and the stored pixel itself."""
     import csv
     cal, neg = pkg.load_calibration(os.path.join(G, "calibration_phase_to_height.json"))
     fm = pkg.load_force_calibration(os.path.join(G, "calibration_height_to_force.json"))["best_model"]
-    al = pkg.FtpAligner(photos[0], max_batch=2)
+    al = pkg.FtpAligner(photos[0], max_batch=2, gray_coeffs=1)
     sensor = pkg.FtpSensor(al.reference_gray_crop, al.circle_crop, pkg.FtpConfig.phase_to_height(), cal, neg, fm, max_batch=2)
     photo = _imread_bgr(os.path.join(G, "Height_2mm_deformed.jpg"))
     rows = pkg.calibrate.phase_to_height_rows(al, sensor, [("Height_2mm_deformed.jpg", photo), ("Height_2mm_deformed.jpg", photo)], [2.07255, 2.07255], batch=2)
@@ -137,5 +138,5 @@ def test_phase_to_height_batch_job_driver(pkg, photos):
     assert rows[0] == rows[1]
     r = rows[0]
     assert r["file"] == stored["file"] and r["depth_mm"] == float(stored["depth_mm"]) and r["heightmap_figure"] == stored["heightmap_figure"]
-    assert abs(r["min_height_unitless"] - float(stored["min_height_unitless"])) <= 1e-3, r
-    assert abs(r["min_x"] - int(stored["min_x"])) <= 1 and abs(r["min_y"] - int(stored["min_y"])) <= 1, r
+    assert abs(r["min_height_unitless"] - float(stored["min_height_unitless"])) <= 5e-4, r
+    assert (r["min_x"], r["min_y"]) == (int(stored["min_x"]), int(stored["min_y"])), r

@@ -165,8 +165,11 @@ def test_arg_extremum_locations_under_phase_to_height_constants():
     photographs, against `Force/Phase_to_height/calibration_out/calibration_results.csv` -- the reference's stored
     arg-extremum ("contact location") goldens.  All four locations are hit exactly (the fourth was one row off, (722, 589) for (722, 588),
     while the oracle's Gaussian rounded its products before adding; with cv's fused multiply-adds the stored pixel comes back and its
-    minimum agrees to 2e-5); the minimum values agree to 3.4e-3 relative (a restated alignment)."""
+    minimum agrees to 2e-5); the minimum values agree to 3.4e-3 relative (a restated alignment).  This data set is reproduced by OpenCV
+    3.x's BGR2GRAY coefficients (with 4.x's the fourth pixel is one row off again and its minimum 2.5e-4 away), the force-path data sets
+    by 4.x's (oracle/align_oracle.py): the report records the generation it was made with."""
     rows = json.load(open(os.path.join(G, "e2e_phase_to_height_report.json")))
+    assert all(r["gray_generation"] == 3 for r in rows)
     assert [r["stored_xy"] for r in rows] == [[703, 514], [607, 524], [729, 537], [722, 588]]
     for r in rows:
         assert r["xy"] == r["stored_xy"]

@@ -20,7 +20,7 @@ NINFO = 12
 
 
 class AlignConfig(ctypes.Structure):
-    _fields_ = [("apply_global_shift", ctypes.c_int32), ("use_ecc", ctypes.c_int32), ("ecc_iters", ctypes.c_int32), ("reserved", ctypes.c_int32),
+    _fields_ = [("apply_global_shift", ctypes.c_int32), ("use_ecc", ctypes.c_int32), ("ecc_iters", ctypes.c_int32), ("gray_coeffs", ctypes.c_int32),
                 ("ecc_eps", ctypes.c_double), ("ecc_gauss_sigma", ctypes.c_double), ("shift_blur_sigma", ctypes.c_double)]
 
 
@@ -46,7 +46,7 @@ class FtpAligner:
     def __init__(self, reference_bgr, circle: Optional[Tuple[int, int, int]] = None,
                  circle_points: Sequence[Tuple[int, int]] = ((1873, 1703), (1599, 707), (2575, 950)),      # shape_ftp.py:41-43
                  apply_global_shift: bool = True, use_ecc: bool = True, ecc_iters: int = 300, ecc_eps: float = 1e-7,
-                 ecc_gauss_sigma: float = 5.0, max_batch: int = 1, device=None):
+                 ecc_gauss_sigma: float = 5.0, max_batch: int = 1, device=None, gray_coeffs: int = 0):
         if not torch.cuda.is_available():
             raise RuntimeError("FtpAligner needs a HIP device (there is no CPU fallback)")
         self._lib = _lib.load()
@@ -61,6 +61,7 @@ class FtpAligner:
         self._lib.vistaf_align_default_config(ctypes.byref(cfg))
         cfg.apply_global_shift = int(apply_global_shift); cfg.use_ecc = int(use_ecc); cfg.ecc_iters = int(ecc_iters)
         cfg.ecc_eps = float(ecc_eps); cfg.ecc_gauss_sigma = float(ecc_gauss_sigma)
+        cfg.gray_coeffs = int(gray_coeffs)       # 0: OpenCV 4.x BGR2GRAY coefficients, 1: OpenCV 3.x (include/vistaf_align.h)
         self.max_batch = int(max_batch)
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):

@@ -2,7 +2,8 @@
 // global shift, fixed-point warpAffine, ROI crop, ECC (euclidean) crop alignment.
 //
 // Arithmetic follows OpenCV 4.x (the test suite checks it against a CPU restatement of the same routines):
-//   * BGR2GRAY on uint8: OpenCV 4.x's 15-bit fixed point, (B*3735 + G*19235 + R*9798 + 2^14) >> 15 (the same form as k_to_gray);
+//   * BGR2GRAY on uint8: OpenCV 4.x's 15-bit fixed point, (B*3735 + G*19235 + R*9798 + 2^14) >> 15 (the same form as k_to_gray), or,
+//     with vistaf_align_config.gray_coeffs = 1, OpenCV 3.x's (R*4899 + G*9617 + B*1868 + 2^13) >> 14;
 //   * phaseCorrelate: sqrt-Hanning window, R2C FFTs (hipFFT), unit-magnitude cross-power spectrum, inverse FFT, arg-max in
 //     fftshift order (first maximum in row-major order), 5x5 weighted centroid, shift = centre - centroid;
 //   * warpAffine INTER_LINEAR: source coordinates in AB_BITS = 10 fixed point, rounded to 1/32 pixel, uint8 through the
@@ -61,12 +62,12 @@ __device__ inline int reflect_b(int p, int n)       // BORDER_REFLECT
     return p;
 }
 
-__global__ void k_bgr2gray(const uint8_t *__restrict__ bgr, uint8_t *__restrict__ g8, float *__restrict__ gf, size_t n)
+__global__ void k_bgr2gray(const uint8_t *__restrict__ bgr, uint8_t *__restrict__ g8, float *__restrict__ gf, size_t n, int coeffs3x)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int b = bgr[3 * i], g = bgr[3 * i + 1], r = bgr[3 * i + 2];
-    int v = (b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15;
+    int v = coeffs3x ? (r * 4899 + g * 9617 + b * 1868 + 8192) >> 14 : (b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15;
     if (g8) g8[i] = (uint8_t)v;
     if (gf) gf[i] = (float)v;
 }
@@ -484,7 +485,7 @@ int vistaf_align_geometry(const vistaf_align_handle *h, int32_t *x1, int32_t *y1
 static int frame_spectrum(vistaf_align_handle *h, const uint8_t *d_bgr, float2 *F, hipStream_t st)
 {
     const size_t FP = (size_t)h->H * h->W;
-    hipLaunchKernelGGL(k_bgr2gray, dim3((unsigned)((FP + 255) / 256)), dim3(256), 0, st, d_bgr, (uint8_t *)nullptr, h->gray_f, FP);
+    hipLaunchKernelGGL(k_bgr2gray, dim3((unsigned)((FP + 255) / 256)), dim3(256), 0, st, d_bgr, (uint8_t *)nullptr, h->gray_f, FP, h->cfg.gray_coeffs);
     launch_gauss_rows(h->gray_f, h->tmp_f, h->g7, h->k7, 1, h->H, h->W, st);
     launch_gauss_cols(h->tmp_f, h->gray_f, h->g7, h->k7, 1, h->H, h->W, st);
     hipLaunchKernelGGL(k_hann_mul, dim3((h->W + 255) / 256, h->H), dim3(256), 0, st, h->gray_f, h->H, h->W);
@@ -509,7 +510,7 @@ int vistaf_align_set_reference(vistaf_align_handle *h, const uint8_t *d_ref_bgr,
     if (rc) return rc;
     const size_t CP = (size_t)h->ch * h->cw;
     hipLaunchKernelGGL(k_crop_bgr, dim3((h->cw + 255) / 256, h->ch), dim3(256), 0, st, d_ref_bgr, h->crop_bgr, h->W, h->x1, h->y1, h->cw);
-    hipLaunchKernelGGL(k_bgr2gray, dim3((unsigned)((CP + 255) / 256)), dim3(256), 0, st, h->crop_bgr, h->ref_gray, (float *)nullptr, CP);
+    hipLaunchKernelGGL(k_bgr2gray, dim3((unsigned)((CP + 255) / 256)), dim3(256), 0, st, h->crop_bgr, h->ref_gray, (float *)nullptr, CP, h->cfg.gray_coeffs);
     hipLaunchKernelGGL(k_circle_mask, dim3((h->cw + 255) / 256, h->ch), dim3(256), 0, st, h->circ, h->ch, h->cw, h->cxl, h->cyl, h->rl);
     // ECC template: ref / 255, GaussianBlur(ecc_gauss)
     hipLaunchKernelGGL(k_u8_to_unit, dim3((unsigned)((CP + 255) / 256)), dim3(256), 0, st, h->ref_gray, h->tpl, CP);
@@ -555,7 +556,7 @@ int vistaf_align_batch(vistaf_align_handle *h, const uint8_t *d_def_bgr, int B, 
         } else {
             hipLaunchKernelGGL(k_crop_bgr, dim3((h->cw + 255) / 256, h->ch), dim3(256), 0, st, bgr, h->crop_bgr, h->W, h->x1, h->y1, h->cw);
         }
-        hipLaunchKernelGGL(k_bgr2gray, dim3((unsigned)((CP + 255) / 256)), dim3(256), 0, st, h->crop_bgr, h->mov_u8 + (size_t)b * CP, (float *)nullptr, CP);
+        hipLaunchKernelGGL(k_bgr2gray, dim3((unsigned)((CP + 255) / 256)), dim3(256), 0, st, h->crop_bgr, h->mov_u8 + (size_t)b * CP, (float *)nullptr, CP, h->cfg.gray_coeffs);
     }
     // ---- align_crop_ecc (:549-578), all frames together
     hipLaunchKernelGGL(k_ecc_init, dim3((B + 63) / 64), dim3(64), 0, st, h->st, B, h->cfg.ecc_eps);

@@ -305,13 +305,16 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit(const float *__restric
 // monomials of degree <= 4, rhs_i likewise.  Same minimisation as the reference's lstsq on (A * w, z * w) (:1119-1121); float64 sums of
 // exact products instead of float32-rounded rows, i.e. closer to the exact solution than either LAPACK's float32 SVD or the first variant.
 // Medians are exact order statistics as before.  The residual plane is evaluated with eval_poly2d's own operation order (:1093-1097).
-template <int RP>
-__global__ __launch_bounds__(SEL_T) void k_robust_polyfit_col(const float *__restrict__ z_all, const uint8_t *__restrict__ mask_all, int order,
+// GT: row groups as a compile-time constant (0: the runtime value).  With a constant stride every yn read is one LDS read at an immediate
+// offset from a single base; with a runtime stride the RP row addresses of a pass are scalar values of their own (hundreds of SGPR spills).
+template <int RP, int NT, int GT>
+__device__ __attribute__((always_inline)) inline void robust_polyfit_col_body(const float *__restrict__ z_all, const uint8_t *__restrict__ mask_all, int order,
                                                               int iters, float c, int min_count, int min_mask_count, float *__restrict__ coef_out,
-                                                              float *__restrict__ resid_all, int h, int w, int cols_pad, int groups)
+                                                              float *__restrict__ resid_all, int h, int w, int cols_pad, int groups_rt)
 {
+    const int groups = GT > 0 ? GT : groups_rt;
     __shared__ SelShared sh;
-    __shared__ double s_part[16][21];
+    __shared__ double s_part[NT / 64][21];
     __shared__ double s_sum[21];
     __shared__ float s_coef[6];
     __shared__ float s_yn[FIT_YTAB];
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit_col(const float *__res
     const float *z = z_all + b * (size_t)P;
     const uint8_t *m = mask_all + b * (size_t)P;
     const float cxf = (float)((w - 1) / 2.0), cyf = (float)((h - 1) / 2.0);
-    for (int i = tid; i < h; i += SEL_T) s_yn[i] = __fdiv_rn(__fsub_rn((float)i, cyf), cyf);
+    for (int i = tid; i < FIT_YTAB; i += NT) s_yn[i] = __fdiv_rn(__fsub_rn((float)i, cyf), cyf);       // rows >= h: only read for samples that are NaN
     const int col = tid % cols_pad, grp = __builtin_amdgcn_readfirstlane(tid / cols_pad);   // uniform inside a wave (cols_pad % 64 == 0)
     const bool owner = col < w && grp < groups;
     const float xn = __fdiv_rn(__fsub_rn((float)col, cxf), cxf);
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit_col(const float *__res
     // the start of every pass -- as loop invariants the RP row coordinates would be hoisted out of the IRLS loop and kept live next to
     // the samples (hundreds of spills)
     auto resid_of = [&](int g0, int u, float zz) -> float {
-        const float yn = s_yn[min(g0 + groups * u, h - 1)];
+        const float yn = s_yn[g0 + groups * u];                      // < FIT_YTAB (checked by the launcher)
         const float fit = __fadd_rn(fmaf(yn, Bt, At), __fmul_rn(coef[5], __fmul_rn(yn, yn)));
         return __fsub_rn(zz, fit);
     };
@@ -391,6 +394,8 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit_col(const float *__res
                 if (mode) r = fabsf(__fsub_rn(r, med));
                 body(f2key(r));
             }
+            // keep the scheduler from hoisting all RP validity masks (an SGPR pair each) and residuals to the top of the pass
+            if ((u & 7) == 7) __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -410,13 +415,14 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit_col(const float *__res
                     const float uu = __fmul_rn(resid_of(g0, u, zz), inv_csig);
                     wt = __fdiv_rn(1.0f, __fadd_rn(1.0f, __fmul_rn(uu, uu)));
                 }
-                const double yd = (double)s_yn[min(g0 + groups * u, h - 1)];
+                const double yd = (double)s_yn[g0 + groups * u];
                 const double w2 = (double)wt * (double)wt;
                 const double t1 = w2 * yd, t2 = t1 * yd, t3 = t2 * yd, t4 = t3 * yd;
                 Pb[0] += w2; Pb[1] += t1; Pb[2] += t2; Pb[3] += t3; Pb[4] += t4;
                 const double zw = w2 * (double)zz;
                 Qb[0] += zw; Qb[1] = fma(zw, yd, Qb[1]); Qb[2] = fma(zw, yd * yd, Qb[2]);
             }
+            if ((u & 7) == 7) __builtin_amdgcn_sched_barrier(0);
         }
         // the 15 monomial sums m[a][b] = sum x^a P_b (a + b <= 4) and the 6 right-hand sides, reduced over the workgroup
         double v21[21];
@@ -438,7 +444,7 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit_col(const float *__res
         __syncthreads();
         if (tid < 21) {
             double v = 0.0;
-            for (int k = 0; k < 16; k++) v += s_part[k][tid];
+            for (int k = 0; k < NT / 64; k++) v += s_part[k][tid];
             s_sum[tid] = v;
         }
         __syncthreads();
@@ -471,14 +477,14 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit_col(const float *__res
             fb = fb * 1.0001f + 1e-30f;
             kmin = f2key(zmin - fb - 1e-6f * fabsf(zmin)); kmax = f2key(zmax + fb + 1e-6f * fabsf(zmax));
         }
-        const float medr = block_median_each(each, sh, n, kmin, kmax);
+        const float medr = block_median_each<NT>(each, sh, n, kmin, kmax);
         __syncthreads();
         med = medr; mode = 1;
         {
             float hi1 = fabsf(__fsub_rn(key2f(kmax), medr)), hi2 = fabsf(__fsub_rn(key2f(kmin), medr));
             kmin = f2key(0.f); kmax = f2key(hi1 > hi2 ? hi1 : hi2);
         }
-        float mad = block_median_each(each, sh, n, kmin, kmax);
+        float mad = block_median_each<NT>(each, sh, n, kmin, kmax);
         __syncthreads();
         mode = 0;
         mad = __fadd_rn(mad, 1e-6f);
@@ -509,25 +515,44 @@ __global__ __launch_bounds__(SEL_T) void k_robust_polyfit_col(const float *__res
     }
 }
 
+#define VF_FIT_ARGS const float *__restrict__ z_all, const uint8_t *__restrict__ mask_all, int order, int iters, float c, int min_count, int min_mask_count, \
+                    float *__restrict__ coef_out, float *__restrict__ resid_all, int h, int w, int cols_pad, int groups
+#define VF_FIT_PASS z_all, mask_all, order, iters, c, min_count, min_mask_count, coef_out, resid_all, h, w, cols_pad, groups
+template <int RP, int GT>
+__global__ __launch_bounds__(SEL_T) void k_robust_polyfit_col(VF_FIT_ARGS) { robust_polyfit_col_body<RP, SEL_T, GT>(VF_FIT_PASS); }
+// register-capped variant (5 waves per SIMD = 96 VGPRs, the rest of the samples' working set spills to scratch): its workgroup fits on a CU
+// NEXT TO the one-wave march (72 VGPRs, 111 KB of LDS) or flood (64, 109 KB) of another session in flight, where the 128-VGPR workgroup
+// needs every register of the CU and has to wait for the march / flood to drain
+template <int RP, int GT>
+__global__ __launch_bounds__(SEL_T) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_robust_polyfit_col_w5(VF_FIT_ARGS) { robust_polyfit_col_body<RP, SEL_T, GT>(VF_FIT_PASS); }
+#undef VF_FIT_ARGS
+#undef VF_FIT_PASS
+
 // min_count: 200 fitted pixels upstream (:1103); min_mask_count: 500 mask pixels for the debug_ramp call (shape_ftp.py:1364-1366), else 0
+// half_wg: 1 = prefer the register-capped variant where it exists (RP 56, four row groups), 0 = 128-VGPR variants only
 void launch_robust_polyfit(const float *z, const uint8_t *mask, int order, int iters, float c, int min_count, int min_mask_count, float *coef_out,
-                           float *resid_out, int B, int h, int w, hipStream_t st)
+                           float *resid_out, int B, int h, int w, hipStream_t st, int half_wg)
 {
     // i / w == umulhi(i, magic) for every i < h * w as long as h * w * w < 2^32
     const uint32_t magic = ((unsigned long long)h * w * w < 0x100000000ull) ? (uint32_t)(0x100000000ull / (unsigned)w) + 1u : 0u;
     const int cols_pad = ((w + 63) / 64) * 64;
+#define VF_FIT_COL(KERNEL, NTV, GR) hipLaunchKernelGGL(KERNEL, dim3(B), dim3(NTV), 0, st, z, mask, order, iters, c, min_count, min_mask_count, coef_out, resid_out, h, w, cols_pad, GR)
     const int groups = cols_pad <= SEL_T ? std::min(SEL_T / cols_pad, h) : 0;
     const int need = groups ? (h + groups - 1) / groups : 1 << 30;
-    if (need <= 64 && h <= FIT_YTAB) {
-#define VF_FIT_COL(RPV) hipLaunchKernelGGL(k_robust_polyfit_col<RPV>, dim3(B), dim3(SEL_T), 0, st, z, mask, order, iters, c, min_count, min_mask_count, coef_out, resid_out, h, w, cols_pad, groups)
-        if (need <= 16) VF_FIT_COL(16);
-        else if (need <= 32) VF_FIT_COL(32);
-        else if (need <= 48) VF_FIT_COL(48);
-        else if (need <= 56) VF_FIT_COL(56);
-        else VF_FIT_COL(64);
-#undef VF_FIT_COL
+    if (need <= 64 && h + groups * 16 <= FIT_YTAB) {
+        if (half_wg == 1 && groups == 4 && need > 48 && need <= 56) VF_FIT_COL((k_robust_polyfit_col_w5<56, 4>), SEL_T, 4);
+        else if (groups == 4 && need > 32) {
+            if (need <= 48) VF_FIT_COL((k_robust_polyfit_col<48, 4>), SEL_T, 4);
+            else if (need <= 56) VF_FIT_COL((k_robust_polyfit_col<56, 4>), SEL_T, 4);
+            else VF_FIT_COL((k_robust_polyfit_col<64, 4>), SEL_T, 4);
+        } else if (need <= 16) VF_FIT_COL((k_robust_polyfit_col<16, 0>), SEL_T, groups);
+        else if (need <= 32) VF_FIT_COL((k_robust_polyfit_col<32, 0>), SEL_T, groups);
+        else if (need <= 48) VF_FIT_COL((k_robust_polyfit_col<48, 0>), SEL_T, groups);
+        else if (need <= 56) VF_FIT_COL((k_robust_polyfit_col<56, 0>), SEL_T, groups);
+        else VF_FIT_COL((k_robust_polyfit_col<64, 0>), SEL_T, groups);
         return;
     }
+#undef VF_FIT_COL
     hipLaunchKernelGGL(k_robust_polyfit, dim3(B), dim3(SEL_T), 0, st, z, mask, order, iters, c, min_count, min_mask_count, coef_out, resid_out, h, w, magic);
 }
 

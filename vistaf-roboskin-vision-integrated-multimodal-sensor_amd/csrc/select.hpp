@@ -61,10 +61,13 @@ __device__ inline uint32_t wave_scan_add(uint32_t v)
 // Finds keys of rank k and k+1 (ascending, 0-based) among the n valid elements.
 // each(body) calls body(key) for every valid element of this thread (the same elements on every call).
 // n must be > 0 and k < n.  Result in all threads.
-template <class Each>
+// NT: threads of the workgroup (a power of two, 256 <= NT <= 1024; the candidate list is limited to NT entries, one per thread of the sort).
+template <int NT = SEL_T, class Each>
 __device__ __attribute__((always_inline)) inline void block_select2_each(Each each, uint32_t n, uint32_t k, SelShared &sh, uint32_t kmin, uint32_t kmax,
                                                                          uint32_t &key_a, uint32_t &key_b)
 {
+    static_assert(NT >= 256 && NT <= SEL_T && (NT & (NT - 1)) == 0, "workgroup size");
+    constexpr uint32_t CAND = NT < SEL_CAND ? NT : SEL_CAND;
     const int tid = threadIdx.x;
     uint32_t lo = kmin, hi = kmax, below = 0;
     uint32_t a = 0, b = 0;
@@ -73,13 +76,13 @@ __device__ __attribute__((always_inline)) inline void block_select2_each(Each ea
         if (range == 0) { a = lo; break; }
         int bits = 32 - __clz(range);
         int shift = bits > SEL_BITS ? bits - SEL_BITS : 0;
-        for (int i = tid; i < SEL_NB; i += SEL_T) sh.hist[i] = 0;
+        for (int i = tid; i < SEL_NB; i += NT) sh.hist[i] = 0;
         __syncthreads();
         each([&](uint32_t key) { if (key >= lo && key <= hi) atomicAdd(&sh.hist[(key - lo) >> shift], 1u); });
         __syncthreads();
         // locate the bucket holding rank (k - below): each thread owns SEL_NB / SEL_T consecutive buckets
         uint32_t want = k - below;
-        constexpr int NBT = SEL_NB / SEL_T;
+        constexpr int NBT = SEL_NB / NT;
         uint32_t cb[NBT];
         uint32_t mine = 0;
 #pragma unroll
@@ -109,7 +112,7 @@ __device__ __attribute__((always_inline)) inline void block_select2_each(Each ea
         lo = nlo; hi = nhi;
         __syncthreads();
         if (shift == 0) { a = lo; break; }
-        if (cnt <= SEL_CAND) {
+        if (cnt <= CAND) {
             // collect candidates of this bucket, rank by counting
             if (tid == 0) sh.s_ncand = 0;
             __syncthreads();
@@ -123,7 +126,7 @@ __device__ __attribute__((always_inline)) inline void block_select2_each(Each ea
                     if (ln == leader) base = atomicAdd(&sh.s_ncand, (uint32_t)__popcll(mk));
                     base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
                     const uint32_t pos = base + (uint32_t)__popcll(mk & ((1ull << ln) - 1ull));
-                    if (pos < SEL_CAND) sh.cand[pos] = key;
+                    if (pos < CAND) sh.cand[pos] = key;
                 }
             });
             __syncthreads();
@@ -131,7 +134,7 @@ __device__ __attribute__((always_inline)) inline void block_select2_each(Each ea
             const uint32_t want2 = k - below;
             if (tid == 0) { sh.s_found = 0; }
             __syncthreads();
-            if (m > SEL_CAND) m = SEL_CAND;                                  // cannot happen (cnt <= SEL_CAND); keeps the indices in range
+            if (m > CAND) m = CAND;                                  // cannot happen (cnt <= SEL_CAND); keeps the indices in range
             // sort the candidates (bitonic network in LDS, padded with the largest key to a power of two >= 64): the two order
             // statistics are then read off by index.  Partners closer than 64 live in the same wave, whose LDS operations execute
             // in order, so only the wider exchanges and the start of a new merge round need a workgroup barrier.
@@ -179,7 +182,7 @@ template <class F>
 __device__ inline void block_select2(F get, int P, uint32_t n, uint32_t k, SelShared &sh, uint32_t kmin, uint32_t kmax,
                                      uint32_t &key_a, uint32_t &key_b)
 {
-    block_select2_each([&](auto body) { sel_foreach(get, P, body); }, n, k, sh, kmin, kmax, key_a, key_b);
+    block_select2_each<SEL_T>([&](auto body) { sel_foreach(get, P, body); }, n, k, sh, kmin, kmax, key_a, key_b);
 }
 
 // count / min / max of valid keys
@@ -235,19 +238,19 @@ __device__ inline float block_percentile(F get, int P, float q32, SelShared &sh,
 }
 
 // np.median of valid elements (mean of the two middle values in float32 for even n)
-template <class Each>
+template <int NT = SEL_T, class Each>
 __device__ __attribute__((always_inline)) inline float block_median_each(Each each, SelShared &sh, uint32_t n, uint32_t kmin, uint32_t kmax)
 {
     if (n == 0) return __uint_as_float(0x7fc00000u);
     if (n == 1) return key2f(kmin);
     uint32_t ka, kb;
-    block_select2_each(each, n, (n & 1u) ? (n - 1) / 2 : n / 2 - 1, sh, kmin, kmax, ka, kb);
+    block_select2_each<NT>(each, n, (n & 1u) ? (n - 1) / 2 : n / 2 - 1, sh, kmin, kmax, ka, kb);
     return (n & 1u) ? key2f(ka) : __fdiv_rn(__fadd_rn(key2f(ka), key2f(kb)), 2.0f);
 }
 template <class F>
 __device__ inline float block_median(F get, int P, SelShared &sh, uint32_t n, uint32_t kmin, uint32_t kmax)
 {
-    return block_median_each([&](auto body) { sel_foreach(get, P, body); }, sh, n, kmin, kmax);
+    return block_median_each<SEL_T>([&](auto body) { sel_foreach(get, P, body); }, sh, n, kmin, kmax);
 }
 
 }  // namespace vf
