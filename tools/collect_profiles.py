@@ -52,7 +52,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         res[k]["launches_" + c] = len(v)
 def find(sub):
     """full kernel name (templates and return type included) of the kernel whose name contains `sub`"""
-    ks = [k for k in res if sub in k]
+    exact = [k for k in res if k.split("::")[-1].split("<")[0].strip() == sub]       # k_telea_window, not k_telea_window_retry
+    ks = exact or [k for k in res if sub in k]
     if not ks:
         raise SystemExit("no counter rows for a kernel named *%s*" % sub)
     return max(ks, key=lambda k: res[k].get("launches_FETCH_SIZE", 0))
@@ -83,5 +84,6 @@ json.dump({"inpaint (k_telea_window)": hbm(want[0]), "unwrap flood (k_unwrap_flo
            "_csrc_sha": bench._csrc_sha(), "_raw": {k: res[k] for k in want}}, open(tp, "w"), indent=1)
 b = json.loads(open(os.path.join(P, f"bench_{rnd}.json")).read())
 s = json.loads(open(os.path.join(P, f"bench_{rnd}_serial.json")).read())
+tel = [r for r in rows if r["Name"].split("(")[0].split("::")[-1].strip() == "k_telea_window"]
 print("default %.0f fps %.2f ms | serial %.0f fps %.2f ms | telea rocprof %.1f us, events %.3f ms" % (
-    b["value"], b["ms_per_step"], s["value"], s["ms_per_step"], float(rows[0]["AverageNs"]) / 1e3, b["roofline"]["kernel_ms"]))
+    b["value"], b["ms_per_step"], s["value"], s["ms_per_step"], float((tel or rows)[0]["AverageNs"]) / 1e3, b["roofline"]["kernel_ms"]))
