@@ -417,6 +417,44 @@ def test_inpaint_window_tier_against_sequential_tier_and_oracle_on_many_frames(p
         assert float(np.abs(img0[b] - di["img_inpainted"]).max()) <= 1e-5 * 255
 
 
+def test_march_lds_tiers_retry_and_whole_frame_fallback(pkg, cal):
+    """The window march runs in three tiers (k_inpaint_win.hip): 110.75 KB of LDS for windows of up to 10 752 cells, the full-size
+    retry (14 464 cells) for the frames the first tier hands back, the whole-frame kernel for the rest.  Saturated spots far apart
+    stretch the bounding window of the hole pixels: frame 1 lands in the retry tier, frame 2 in the whole-frame kernel, frame 0
+    stays in the first tier.  All three must equal the oracle at the strict bar, the inpainted planes bit for bit with the two-tier
+    front end on and off."""
+    n = 224
+    cfg = pkg.FtpConfig.scaled(n)
+    ref, sensor = _sensor(pkg, cal, n, cfg, 3, config=3)
+    frames = pkg.synth.deformed_batch(n, 300, 3, config=3).copy()
+    yy, xx = np.mgrid[0:n, 0:n]
+    for b, spots in ((1, ((66, 66), (160, 158))), (2, ((45, 47), (182, 178)))):
+        for (cy, cx) in spots:
+            frames[b][(yy - cy) ** 2 + (xx - cx) ** 2 <= 9] = 255
+    out = sensor.predict_batch(frames)
+    torch.cuda.synchronize()
+    P = n * n
+    bad = sensor.intermediate("bad1", 3, torch.uint8).cpu().numpy().reshape(3, n, n) != 0
+    img_a = sensor.intermediate("img", 3).cpu().numpy().reshape(3, n, n).copy()
+    rng_px = int(round(cfg.bad_inpaint_radius))
+    cells = []
+    for b in range(3):
+        ys, xs = np.where(bad[b])
+        cells.append((ys.max() - ys.min() + 1 + 2 * (rng_px + 1)) * (xs.max() - xs.min() + 1 + 2 * (rng_px + 1)))
+    assert cells[0] <= 10752 < cells[1] <= 14464 < cells[2], cells
+    rs = O.make_reference_state(ref, *pkg.synth.roi_circle(n), cfg)
+    for b in range(3):
+        o = O.process_frame(frames[b], rs, cfg, *cal, keep_intermediates=True)
+        di = o["inter"]["demod"]["inter"]
+        assert np.array_equal(bad[b], di["bad"]), b
+        assert np.array_equal(img_a[b], di["img_inpainted"]), b            # OpenCV's summation order in every tier: same bits
+        _check_frame(out, b, o, n)
+    sensor._test_set("telea_two_tier", 0)
+    sensor.predict_batch(frames)
+    torch.cuda.synchronize()
+    assert np.array_equal(sensor.intermediate("img", 3).cpu().numpy().reshape(3, n, n), img_a)
+
+
 def test_sixty_four_more_frames_against_oracle(pkg, cal):
     """Breadth: 64 further synthetic frames (two amplitude scales) end to end against the oracle, EVERY frame at the strict bar of the
     other tests (map within 1e-4 of its peak, masks equal, arg-max index equal).  Guards the data-dependent kernels (run-based
