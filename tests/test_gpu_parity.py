@@ -188,6 +188,48 @@ def test_unwrap_with_true_wraps_and_parent_tree(pkg, cal):
     assert saw_wrap
 
 
+def test_big_frame_flood_reproduces_the_heap_order(pkg, cal):
+    """Frames beyond the uint16 rank range (here 320 x 320 = 103 684 padded pixels; the native crops have 1.4 M) take the bitmap flood of
+    k_unwrap_big.hip: 32-bit ranks, priority queue as a three-level bitmap in LDS, plane in global memory, up to 8 pops per step.
+    Deformations of several 2*pi; the parent of every pixel must equal the reference heap's, bit for bit, and the generic one-pop
+    kernel (test hook flood_tier = 0) must give the same tree."""
+    n, nb = 320, 2
+    cfg = pkg.FtpConfig.scaled(n)
+    ref, sensor = _sensor(pkg, cal, n, cfg, nb, config=5)
+    frames = pkg.synth.deformed_batch(n, 0, nb, config=5, amp_scale=9.0)
+    out = sensor.predict_batch(frames)
+    torch.cuda.synchronize()
+    rs = O.make_reference_state(ref, *pkg.synth.roi_circle(n), cfg)
+    P = n * n
+    uw_all = sensor.intermediate("unwrapped", nb).cpu().numpy().copy()
+    wr_all = sensor.intermediate("wrapped", nb).cpu().numpy().copy()
+    par_all = sensor.intermediate("parent", nb, torch.int32).cpu().numpy().copy()
+    qg_all = sensor.intermediate("quality", nb).cpu().numpy().copy()
+    from oracle import cvlite
+    saw_wrap = False
+    for b in range(nb):
+        o = O.process_frame(frames[b], rs, cfg, *cal, keep_intermediates=True)
+        it = o["inter"]
+        uo = it["unwrapped"]
+        uw = uw_all[b * P:(b + 1) * P].reshape(n, n)
+        wr = wr_all[b * P:(b + 1) * P].reshape(n, n)
+        assert np.array_equal(np.isnan(uw), np.isnan(uo))
+        m = ~np.isnan(uo)
+        k_gpu = np.rint((uw[m] - wr[m]) / (2 * np.pi))
+        k_ora = np.rint((uo[m] - it["wrapped"][m]) / (2 * np.pi))
+        assert np.array_equal(k_gpu, k_ora)
+        saw_wrap |= bool(np.any(k_ora != 0))
+        _, par_o, _ = cvlite.unwrap_quality_guided(it["wrapped"], o["reliable"], it["quality"], want_tree=True)
+        assert np.array_equal(qg_all[b * P:(b + 1) * P].reshape(n, n)[rs["roi"]], it["quality"][rs["roi"]])
+        assert np.array_equal(par_all[b * P:(b + 1) * P].reshape(n, n), par_o), b
+        _check_frame(out, b, o, n)
+    assert saw_wrap
+    sensor._test_set("flood_tier", 0)
+    sensor.predict_batch(frames)
+    torch.cuda.synchronize()
+    assert np.array_equal(sensor.intermediate("parent", nb, torch.int32).cpu().numpy(), par_all)
+
+
 def test_input_formats_agree(pkg, cal):
     n, nb = 128, 2
     cfg = pkg.FtpConfig.scaled(n)

@@ -25,11 +25,12 @@ __device__ inline uint8_t ld_st(const uint8_t *st, int i, bool lds)
 template <bool LS>
 __global__ __launch_bounds__(64) void k_unwrap_flood(const float *__restrict__ quality_all, const uint8_t *__restrict__ mask_all,
                                                      int32_t *__restrict__ parent_all, uint8_t *gst, uint32_t *gfq, uint32_t *gfi,
-                                                     int cap, int32_t *status, int h, int w)
+                                                     int cap, int32_t *status, int h, int w, const int32_t *__restrict__ only)
 {
     extern __shared__ unsigned char lds_raw[];
     const int lane = threadIdx.x;
     const size_t b = blockIdx.x;
+    if (only && !only[b]) return;                    // big-frame path: only the frames the bitmap flood handed back
     const int P = h * w;
     const float *quality = quality_all + b * (size_t)P;
     const uint8_t *mask = mask_all + b * (size_t)P;
@@ -129,11 +130,13 @@ __device__ inline unsigned long long ld_u64c(const unsigned long long *p) { retu
 __device__ inline void st_u64c(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __global__ __launch_bounds__(1024) void k_unwrap_tree(const float *__restrict__ wrapped_all, int32_t *parent_all,
-                                                      const int32_t *__restrict__ ppar_all, size_t gstride, unsigned long long *words_all,
-                                                      float *__restrict__ unwrapped_all, int h, int w)
+                                                      const int32_t *__restrict__ ppar_in, size_t gstride, unsigned long long *words_all,
+                                                      float *__restrict__ unwrapped_all, int h, int w, const int32_t *__restrict__ plain_parents)
 {
     __shared__ int s_changed;
     const size_t b = blockIdx.x;
+    // plain_parents[b] != 0: this frame's parents were written to parent_all directly (generic flood), not to the padded plane
+    const int32_t *ppar_all = (plain_parents && plain_parents[b]) ? nullptr : ppar_in;
     const int P = h * w;
     const float *wrapped = wrapped_all + b * (size_t)P;
     int32_t *tree = parent_all + b * (size_t)P;
@@ -203,7 +206,8 @@ __global__ __launch_bounds__(1024) void k_unwrap_tree(const float *__restrict__ 
 size_t unwrap_scratch_bytes_per_frame(int h, int w)
 {
     size_t P = (size_t)h * w, EN = (size_t)(h + 2) * (w + 2);
-    return P /*st*/ + 5 * EN * sizeof(uint32_t) /*sort / frontier / jump buffers / padded parents*/ + 2 * EN + 16 /*rank codes*/ + 64 /*seed*/ + 512;
+    const size_t code_bytes = EN > 65533 ? 4 * EN + 32 : 2 * EN + 16;     // uint32 rank codes for frames beyond the uint16 range
+    return P /*st*/ + 5 * EN * sizeof(uint32_t) /*sort / frontier / jump buffers / padded parents*/ + code_bytes /*rank codes*/ + 64 /*seed, n, flag*/ + 512;
 }
 
 bool unwrap_ranked_supported(int h, int w);
@@ -212,6 +216,11 @@ bool launch_unwrap_ranked(const float *quality, const uint8_t *mask, uint32_t *g
                           hipStream_t st, hipEvent_t ev_flood, int flood_tier);
 void launch_unwrap_replay(const float *wrapped, const uint32_t *order, size_t ostride, const int32_t *ppar, size_t gstride, int32_t *tree,
                           float *unwrapped, int B, int h, int w, hipStream_t st);
+bool unwrap_big_supported(int h, int w);
+void launch_unwrap_rank32(const float *quality, const uint8_t *mask, uint32_t *gA, uint32_t *gB, size_t gstride, uint32_t *rank32, int32_t *seed,
+                          int32_t *n_out, int B, int h, int w, hipStream_t st);
+void launch_unwrap_flood_big(uint32_t *code, const int32_t *seed, const int32_t *n, const uint32_t *inv, size_t inv_stride, int32_t *ppar,
+                             size_t gstride, int32_t *need_generic, int B, int h, int w, hipStream_t st);
 
 static int unwrap_lds_cap(int P)
 {
@@ -245,19 +254,36 @@ void launch_unwrap(const float *wrapped, const float *quality, const uint8_t *ma
             launch_unwrap_replay(wrapped, g2, 2 * EN, ppar, EN, parent, unwrapped, B, h, w, st);
             return;
         }
+    } else if (unwrap_big_supported(h, w) && flood_tier == 2) {
+        // frames beyond the uint16 rank range (native crops): 32-bit ranks, bitmap priority queue in LDS, plane in global memory
+        // (k_unwrap_big.hip); masks too large for the bitmap go through the generic kernel below, frame by frame
+        uint8_t *after = (uint8_t *)(g4 + gn);
+        after = (uint8_t *)(((uintptr_t)after + 255) & ~(uintptr_t)255);
+        uint32_t *rank32 = (uint32_t *)after;
+        int32_t *seed = (int32_t *)(after + (((gn + 8 * (size_t)B) * 4 + 255) & ~(size_t)255));
+        int32_t *nmask = seed + B, *need_generic = nmask + B;
+        launch_unwrap_rank32(quality, mask, g0, g2, EN, rank32, seed, nmask, B, h, w, st);
+        if (ev_flood) hipEventRecord(ev_flood, st);
+        launch_unwrap_flood_big(rank32, seed, nmask, g0, 2 * EN, (int32_t *)g4, EN, need_generic, B, h, w, st);
+        // (the generic kernel's frontier arrays reuse g0 | g1: the sorted indices are dead by now)
+        hipLaunchKernelGGL(k_unwrap_flood<false>, dim3(B), dim3(64), 0, st, quality, mask, parent, gst, g0, g1, P, status, h, w, need_generic);
+        if (ev_mid) hipEventRecord(ev_mid, st);
+        hipLaunchKernelGGL(k_unwrap_tree, dim3(B), dim3(1024), 0, st, wrapped, parent, (const int32_t *)g4, EN, (unsigned long long *)g0, unwrapped, h, w,
+                           need_generic);
+        return;
     } else if (cap > 0) {
         if (ev_flood) hipEventRecord(ev_flood, st);
         static DynLdsOnce lds_once;
         ensure_dyn_lds(lds_once, (const void *)k_unwrap_flood<true>, 160 * 1024);
         size_t lds = (size_t)cap * 8 + ((P + 15) & ~15);
-        hipLaunchKernelGGL(k_unwrap_flood<true>, dim3(B), dim3(64), lds, st, quality, mask, parent, gst, g0, g1, cap, status, h, w);
+        hipLaunchKernelGGL(k_unwrap_flood<true>, dim3(B), dim3(64), lds, st, quality, mask, parent, gst, g0, g1, cap, status, h, w, (const int32_t *)nullptr);
     } else {
         if (ev_flood) hipEventRecord(ev_flood, st);
-        hipLaunchKernelGGL(k_unwrap_flood<false>, dim3(B), dim3(64), 0, st, quality, mask, parent, gst, g0, g1, P, status, h, w);
+        hipLaunchKernelGGL(k_unwrap_flood<false>, dim3(B), dim3(64), 0, st, quality, mask, parent, gst, g0, g1, P, status, h, w, (const int32_t *)nullptr);
     }
     if (ev_mid) hipEventRecord(ev_mid, st);
     // g0|g1 (2 x B*EN uint32, contiguous) hold the per-pixel 64-bit words; stride EN words per frame
-    hipLaunchKernelGGL(k_unwrap_tree, dim3(B), dim3(1024), 0, st, wrapped, parent, ppar, EN, (unsigned long long *)g0, unwrapped, h, w);
+    hipLaunchKernelGGL(k_unwrap_tree, dim3(B), dim3(1024), 0, st, wrapped, parent, ppar, EN, (unsigned long long *)g0, unwrapped, h, w, (const int32_t *)nullptr);
 }
 
 }  // namespace vf

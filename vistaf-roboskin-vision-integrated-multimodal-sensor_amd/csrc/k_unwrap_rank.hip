@@ -64,10 +64,13 @@ __device__ inline unsigned long long ld_u64c(const unsigned long long *p) { retu
 constexpr int RK_BITS = 11, RK_NB = 1 << RK_BITS;   // 3 passes of 11 bits over the 32-bit keys
 constexpr int RK_U = 4;        // 64-element tiles in flight per wave (independent loads issued together)
 
-__global__ __launch_bounds__(RK_T) void k_unwrap_rank(const float *__restrict__ quality_all, const uint8_t *__restrict__ mask_all,
-                                                      unsigned long long *A_all, unsigned long long *B_all,
-                                                      size_t gstride, uint16_t *__restrict__ rank_all, int32_t *__restrict__ seed_out,
-                                                      int h, int w)
+// CodeT = uint16_t: frames of up to 65533 padded pixels (the LDS-resident floods); uint32_t: larger frames (k_unwrap_big.hip), which also
+// get the number of masked pixels in n_out
+template <typename CodeT>
+__device__ __attribute__((always_inline)) inline void unwrap_rank_body(const float *__restrict__ quality_all, const uint8_t *__restrict__ mask_all,
+                                                                       unsigned long long *A_all, unsigned long long *B_all, size_t gstride,
+                                                                       CodeT *__restrict__ rank_all, int32_t *__restrict__ seed_out,
+                                                                       int32_t *__restrict__ n_out, int h, int w)
 {
     // sort records: key << 32 | padded pixel index (one 8-byte scattered store per element and pass)
     extern __shared__ uint32_t rk_lds[];
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(RK_T) void k_unwrap_rank(const float *__restrict__ 
     const uint8_t *m = mask_all + b * (size_t)P;
     unsigned long long *rA = A_all + b * gstride, *rB = B_all + b * gstride;
     uint32_t *inv = (uint32_t *)rA;             // three passes leave the records in rB: rA is free for the sorted pixel indices
-    uint16_t *rk = rank_all + b * (size_t)((EN + 7) & ~7);
+    CodeT *rk = rank_all + b * (size_t)((EN + 7) & ~7);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     for (int i = tid; i < EN; i += RK_T) rk[i] = 0;
@@ -123,6 +126,7 @@ __global__ __launch_bounds__(RK_T) void k_unwrap_rank(const float *__restrict__ 
         }
     }
     if (tid == 0 && n == 0) seed_out[b] = -1;
+    if (tid == 0 && n_out) n_out[b] = (int32_t)n;
     __threadfence_block();
     __syncthreads();
     if (n == 0) return;
@@ -193,10 +197,32 @@ __global__ __launch_bounds__(RK_T) void k_unwrap_rank(const float *__restrict__ 
     // 3. rank = sorted position (ascending priority); uint16 code = rank + 3; inv[rank] = padded pixel index
     for (int e = tid; e < (int)n; e += RK_T) {
         uint32_t ix = (uint32_t)ld_u64c(&rs[e]);
-        rk[ix] = (uint16_t)(e + 3);
+        rk[ix] = (CodeT)(e + 3);
         inv[e] = ix;
         if (e == (int)n - 1) seed_out[b] = (int32_t)ix;
     }
+}
+__global__ __launch_bounds__(RK_T) void k_unwrap_rank(const float *__restrict__ quality_all, const uint8_t *__restrict__ mask_all,
+                                                      unsigned long long *A_all, unsigned long long *B_all, size_t gstride,
+                                                      uint16_t *__restrict__ rank_all, int32_t *__restrict__ seed_out, int h, int w)
+{
+    unwrap_rank_body<uint16_t>(quality_all, mask_all, A_all, B_all, gstride, rank_all, seed_out, nullptr, h, w);
+}
+__global__ __launch_bounds__(RK_T) void k_unwrap_rank32(const float *__restrict__ quality_all, const uint8_t *__restrict__ mask_all,
+                                                        unsigned long long *A_all, unsigned long long *B_all, size_t gstride,
+                                                        uint32_t *__restrict__ rank_all, int32_t *__restrict__ seed_out, int32_t *__restrict__ n_out,
+                                                        int h, int w)
+{
+    unwrap_rank_body<uint32_t>(quality_all, mask_all, A_all, B_all, gstride, rank_all, seed_out, n_out, h, w);
+}
+// ranks of frames too large for uint16 codes: 32-bit codes in a padded plane, sorted pixel indices in A (uint32, stride 2 * gstride)
+void launch_unwrap_rank32(const float *quality, const uint8_t *mask, uint32_t *gA, uint32_t *gB, size_t gstride, uint32_t *rank32, int32_t *seed,
+                          int32_t *n_out, int B, int h, int w, hipStream_t st)
+{
+    static DynLdsOnce rank_once;
+    ensure_dyn_lds(rank_once, (const void *)k_unwrap_rank32, 16 * RK_NB * (int)sizeof(uint32_t));
+    hipLaunchKernelGGL(k_unwrap_rank32, dim3(B), dim3(RK_T), (size_t)16 * RK_NB * sizeof(uint32_t), st, quality, mask, (unsigned long long *)gA,
+                       (unsigned long long *)gB, gstride, rank32, seed, n_out, h, w);
 }
 
 // ---- growth --------------------------------------------------------------------------------------------
