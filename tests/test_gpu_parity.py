@@ -224,10 +224,12 @@ def test_big_frame_flood_reproduces_the_heap_order(pkg, cal):
         assert np.array_equal(par_all[b * P:(b + 1) * P].reshape(n, n), par_o), b
         _check_frame(out, b, o, n)
     assert saw_wrap
-    sensor._test_set("flood_tier", 0)
-    sensor.predict_batch(frames)
-    torch.cuda.synchronize()
-    assert np.array_equal(sensor.intermediate("parent", nb, torch.int32).cpu().numpy(), par_all)
+    for tier in (0, 3):       # 0: generic kernel only; 3: bitmap flood hands every frame back (the path of masks larger than its bitmap)
+        sensor._test_set("flood_tier", tier)
+        sensor.predict_batch(frames)
+        torch.cuda.synchronize()
+        assert np.array_equal(sensor.intermediate("parent", nb, torch.int32).cpu().numpy(), par_all), tier
+        assert np.array_equal(sensor.intermediate("unwrapped", nb).cpu().numpy(), uw_all, equal_nan=True), tier
 
 
 def test_input_formats_agree(pkg, cal):

@@ -787,7 +787,7 @@ int vistaf_ftp_test_set(vistaf_ftp_handle *hd, const char *name, int value)
     if (!hd || !name) return fail(VISTAF_E_INVALID, "null argument");
     const std::string n(name);
     if (n == "inpaint_tier" && value >= 0 && value <= 2) hd->tiers.inpaint = value;
-    else if (n == "flood_tier" && value >= 0 && value <= 2) hd->tiers.flood = value;
+    else if (n == "flood_tier" && value >= 0 && value <= 3) hd->tiers.flood = value;
     else if (n == "chamfer_twopass") hd->tiers.chamfer_twopass = value != 0;
     else if (n == "telea_two_tier") hd->tiers.telea_two_tier = value != 0;
     else if (n == "fit_half_wg") hd->tiers.fit_half_wg = value != 0;

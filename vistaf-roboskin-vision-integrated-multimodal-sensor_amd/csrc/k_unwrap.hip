@@ -220,7 +220,7 @@ bool unwrap_big_supported(int h, int w);
 void launch_unwrap_rank32(const float *quality, const uint8_t *mask, uint32_t *gA, uint32_t *gB, size_t gstride, uint32_t *rank32, int32_t *seed,
                           int32_t *n_out, int B, int h, int w, hipStream_t st);
 void launch_unwrap_flood_big(uint32_t *code, const int32_t *seed, const int32_t *n, const uint32_t *inv, size_t inv_stride, int32_t *ppar,
-                             size_t gstride, int32_t *need_generic, int B, int h, int w, hipStream_t st);
+                             size_t gstride, int32_t *need_generic, bool force_generic, int B, int h, int w, hipStream_t st);
 
 static int unwrap_lds_cap(int P)
 {
@@ -254,7 +254,7 @@ void launch_unwrap(const float *wrapped, const float *quality, const uint8_t *ma
             launch_unwrap_replay(wrapped, g2, 2 * EN, ppar, EN, parent, unwrapped, B, h, w, st);
             return;
         }
-    } else if (unwrap_big_supported(h, w) && flood_tier == 2) {
+    } else if (unwrap_big_supported(h, w) && flood_tier >= 2) {
         // frames beyond the uint16 rank range (native crops): 32-bit ranks, bitmap priority queue in LDS, plane in global memory
         // (k_unwrap_big.hip); masks too large for the bitmap go through the generic kernel below, frame by frame
         uint8_t *after = (uint8_t *)(g4 + gn);
@@ -264,7 +264,7 @@ void launch_unwrap(const float *wrapped, const float *quality, const uint8_t *ma
         int32_t *nmask = seed + B, *need_generic = nmask + B;
         launch_unwrap_rank32(quality, mask, g0, g2, EN, rank32, seed, nmask, B, h, w, st);
         if (ev_flood) hipEventRecord(ev_flood, st);
-        launch_unwrap_flood_big(rank32, seed, nmask, g0, 2 * EN, (int32_t *)g4, EN, need_generic, B, h, w, st);
+        launch_unwrap_flood_big(rank32, seed, nmask, g0, 2 * EN, (int32_t *)g4, EN, need_generic, flood_tier == 3, B, h, w, st);
         // (the generic kernel's frontier arrays reuse g0 | g1: the sorted indices are dead by now)
         hipLaunchKernelGGL(k_unwrap_flood<false>, dim3(B), dim3(64), 0, st, quality, mask, parent, gst, g0, g1, P, status, h, w, need_generic);
         if (ev_mid) hipEventRecord(ev_mid, st);

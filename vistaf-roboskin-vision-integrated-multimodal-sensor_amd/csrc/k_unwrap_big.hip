@@ -34,7 +34,8 @@ __device__ inline int bg_top(unsigned long long v) { return 63 - __clzll((long l
 
 __global__ __launch_bounds__(64) void k_unwrap_flood_big(uint32_t *__restrict__ code_all, const int32_t *__restrict__ seed_in,
                                                          const int32_t *__restrict__ n_in, const uint32_t *__restrict__ inv_all, size_t inv_stride,
-                                                         int32_t *__restrict__ ppar_all, size_t gstride, int32_t *__restrict__ need_generic, int h, int w)
+                                                         int32_t *__restrict__ ppar_all, size_t gstride, int32_t *__restrict__ need_generic, int max_ranks,
+                                                         int h, int w)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long *L0 = (unsigned long long *)lds_raw;
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_big(uint32_t *__restrict__ 
     for (int p = lane; p < EN; p += 64) ppar[p] = -1;
     if (lane == 0) need_generic[b] = 0;
     if (seed < 0 || n <= 0) return;                                      // empty mask (shape_ftp.py:1047-1048)
-    if (n > BG_NW0 * 64) { if (lane == 0) need_generic[b] = 1; return; }
+    if (n > max_ranks) { if (lane == 0) need_generic[b] = 1; return; }       // mask larger than the bitmap: the generic kernel takes the frame
     for (int i = lane; i < BG_NW0 + BG_NW1 + BG_NW2; i += 64) L0[i] = 0ull;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __syncthreads();
@@ -184,13 +185,15 @@ bool unwrap_big_supported(int h, int w)
     return EN > 65533 && EN < (1L << 26);
 }
 
+// force_generic (test hook flood_tier = 3): hand every frame back, which exercises the per-frame fallback plumbing at small sizes
 void launch_unwrap_flood_big(uint32_t *code, const int32_t *seed, const int32_t *n, const uint32_t *inv, size_t inv_stride, int32_t *ppar,
-                             size_t gstride, int32_t *need_generic, int B, int h, int w, hipStream_t st)
+                             size_t gstride, int32_t *need_generic, bool force_generic, int B, int h, int w, hipStream_t st)
 {
     const size_t lds = (size_t)(BG_NW0 + BG_NW1 + BG_NW2) * 8 + 64;
     static DynLdsOnce lds_once;
     ensure_dyn_lds(lds_once, (const void *)k_unwrap_flood_big, 160 * 1024);
-    hipLaunchKernelGGL(k_unwrap_flood_big, dim3(B), dim3(64), lds, st, code, seed, n, inv, inv_stride, ppar, gstride, need_generic, h, w);
+    hipLaunchKernelGGL(k_unwrap_flood_big, dim3(B), dim3(64), lds, st, code, seed, n, inv, inv_stride, ppar, gstride, need_generic,
+                       force_generic ? 0 : BG_NW0 * 64, h, w);
 }
 
 }  // namespace vf

@@ -11,7 +11,7 @@ namespace vf {
 // sizes the defaults do not cover and stay selectable so the parity tests can pin them against the defaults (csrc/test_hooks.h).
 struct Tiers {
     int inpaint = 2;            // 2: frame-window march (k_telea_window) + whole-frame fallback; 1: whole-frame kernel only; 0: cluster front end first
-    int flood = 2;              // 2: batched pops (k_unwrap_flood_batch); 1: one pop per step (k_unwrap_flood_hot); 0: frontier scan
+    int flood = 2;              // 2: batched pops (k_unwrap_flood_batch / k_unwrap_flood_big); 1: one pop per step (k_unwrap_flood_hot); 0: frontier scan; 3: test only (test_hooks.h)
     int chamfer_twopass = 0;    // 1: force the one-wave two-pass chamfer even where the LDS closed form applies
     int fit_half_wg = 1;        // 1: register-capped column polyfit (fits on a CU next to a march / flood wave); 0: 128-VGPR variant
     int telea_two_tier = 1;     // 1: 111 KB first tier of the window march + full-size retry of the frames it hands back; 0: full size only

@@ -8,7 +8,8 @@
 extern "C" {
 #endif
 /* name: "inpaint_tier"  2 window march + whole-frame fallback (default), 1 whole-frame kernel only, 0 cluster front end first
- *       "flood_tier"    2 batched pops (default), 1 one pop per step, 0 frontier scan
+ *       "flood_tier"    2 batched pops (default), 1 one pop per step, 0 frontier scan; 3 (frames beyond the uint16 rank range only): the
+ *                       bitmap flood hands every frame back to the generic kernel, as it does for masks larger than its bitmap
  *       "chamfer_twopass" 1 forces the one-wave two-pass chamfer transform
  *       "telea_two_tier" 1 (default) 111 KB first tier of the window march + full-size retry, 0 full-size march only
  *       "fit_half_wg"   1 (default) register-capped column polyfit that shares a CU with a march / flood wave, 0 the 128-VGPR variant
