@@ -168,3 +168,18 @@ def test_fft_precision_modes_agree():
         ha, hb = a["height_map_mm_crop"], b["height_map_mm_crop"]
         assert np.nanmax(np.abs(ha - hb)) <= 1e-3 * np.nanmax(np.abs(ha))
         assert a["argmax_depth_index"] == b["argmax_depth_index"]
+
+
+def test_bgr2gray_generations():
+    """cv2.cvtColor(BGR2GRAY) on uint8: OpenCV 4.x's 15-bit and 3.x's 14-bit coefficients differ by one unit for 43 864 of the 2^24 colours
+    (oracle/align_oracle.py: the reference pins no version, its stored outputs pick the generation per data set); both map greys to
+    themselves, and 4.x is the default"""
+    from oracle import align_oracle as A
+    v = np.arange(256, dtype=np.uint8)
+    grey = np.stack([v, v, v], -1)[None]
+    assert np.array_equal(A.bgr2gray_u8(grey, 4)[0], v) and np.array_equal(A.bgr2gray_u8(grey, 3)[0], v)
+    b, g, r = np.meshgrid(v, v, v, indexing="ij")
+    cube = np.stack([b, g, r], -1).reshape(256, 65536, 3)
+    g4, g3 = A.bgr2gray_u8(cube, 4).astype(np.int16), A.bgr2gray_u8(cube, 3).astype(np.int16)
+    assert int((g4 != g3).sum()) == 43864 and int(np.abs(g4 - g3).max()) == 1
+    assert np.array_equal(A.bgr2gray_u8(cube), g4.astype(np.uint8))
