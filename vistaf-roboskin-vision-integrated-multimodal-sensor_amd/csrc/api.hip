@@ -559,10 +559,10 @@ static int post_demod(vistaf_ftp_handle *hd, int B, float *d_height_mm, uint8_t 
     if (timed) hipEventRecord(hd->ev[ST_DETREND], st);
     if (c.plane_order_for_removal > 0)
         // debug_ramp gates on the reliable count, NaN pixels included (:1364-1366), robust_polyfit2d on 200 finite samples (:1103)
-        launch_robust_polyfit(hd->unwrapped, hd->reliable, c.plane_order_for_removal, c.irls_iters, (float)c.irls_c, 200, 500, hd->coef, hd->phase1, B, h, w, st, hd->tiers.fit_half_wg);
+        launch_robust_polyfit(hd->unwrapped, hd->reliable, c.plane_order_for_removal, c.irls_iters, (float)c.irls_c, 200, 500, hd->coef, hd->phase1, B, h, w, st, hd->tiers.fit_capped);
     else   // no debug_ramp (the constants of Code/phase_to_height.py): the unwrapped phase goes to the detrend as it is
         HIPCHK(hipMemcpyAsync(hd->phase1, hd->unwrapped, (size_t)B * P * sizeof(float), hipMemcpyDeviceToDevice, st));
-    launch_robust_polyfit(hd->phase1, hd->reliable, c.poly_order, c.irls_iters, (float)c.irls_c, 200, 0, hd->coef, hd->resid0, B, h, w, st, hd->tiers.fit_half_wg);
+    launch_robust_polyfit(hd->phase1, hd->reliable, c.poly_order, c.irls_iters, (float)c.irls_c, 200, 0, hd->coef, hd->resid0, B, h, w, st, hd->tiers.fit_capped);
     launch_select(hd->resid0, hd->reliable, (size_t)P, nullptr, true, hd->req_contact, 3, hd->thr3, nullptr, B, P, st);
     launch_contact_mask(hd->resid0, hd->reliable, hd->thr3, hd->rel_count, hd->contact_count, (float)c.min_contact_frac, (float)c.max_contact_frac,
                         hd->contact, hd->thr_used, B, P, st);
@@ -583,7 +583,7 @@ static int post_demod(vistaf_ftp_handle *hd, int B, float *d_height_mm, uint8_t 
         }
     }
     launch_background(hd->reliable, hd->contact_d, hd->rel_count, hd->bg_count, hd->background, B, P, st);
-    launch_robust_polyfit(hd->phase1, hd->background, c.poly_order, c.irls_iters, (float)c.irls_c, 200, 0, hd->coef, hd->detr, B, h, w, st, hd->tiers.fit_half_wg);
+    launch_robust_polyfit(hd->phase1, hd->background, c.poly_order, c.irls_iters, (float)c.irls_c, 200, 0, hd->coef, hd->detr, B, h, w, st, hd->tiers.fit_capped);
     launch_select(hd->detr, hd->background, (size_t)P, nullptr, false, hd->req_med, 1, hd->bg_med, nullptr, B, P, st);
 
     // ---- reliable-only smoothing + sign flip (shape_ftp.py:1753-1768)
@@ -790,7 +790,7 @@ int vistaf_ftp_test_set(vistaf_ftp_handle *hd, const char *name, int value)
     else if (n == "flood_tier" && value >= 0 && value <= 3) hd->tiers.flood = value;
     else if (n == "chamfer_twopass") hd->tiers.chamfer_twopass = value != 0;
     else if (n == "telea_two_tier") hd->tiers.telea_two_tier = value != 0;
-    else if (n == "fit_half_wg") hd->tiers.fit_half_wg = value != 0;
+    else if (n == "fit_capped") hd->tiers.fit_capped = value != 0;
     else if (n == "keep_planes") hd->keep_planes = value != 0;
     else return fail(VISTAF_E_INVALID, "unknown test hook or value: " + n);
     return 0;

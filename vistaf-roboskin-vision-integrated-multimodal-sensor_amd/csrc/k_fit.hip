@@ -394,8 +394,6 @@ __device__ __attribute__((always_inline)) inline void robust_polyfit_col_body(co
                 if (mode) r = fabsf(__fsub_rn(r, med));
                 body(f2key(r));
             }
-            // keep the scheduler from hoisting all RP validity masks (an SGPR pair each) and residuals to the top of the pass
-            if ((u & 7) == 7) __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -422,7 +420,6 @@ __device__ __attribute__((always_inline)) inline void robust_polyfit_col_body(co
                 const double zw = w2 * (double)zz;
                 Qb[0] += zw; Qb[1] = fma(zw, yd, Qb[1]); Qb[2] = fma(zw, yd * yd, Qb[2]);
             }
-            if ((u & 7) == 7) __builtin_amdgcn_sched_barrier(0);
         }
         // the 15 monomial sums m[a][b] = sum x^a P_b (a + b <= 4) and the 6 right-hand sides, reduced over the workgroup
         double v21[21];
@@ -529,9 +526,9 @@ __global__ __launch_bounds__(SEL_T) __attribute__((amdgpu_waves_per_eu(5, 5))) v
 #undef VF_FIT_PASS
 
 // min_count: 200 fitted pixels upstream (:1103); min_mask_count: 500 mask pixels for the debug_ramp call (shape_ftp.py:1364-1366), else 0
-// half_wg: 1 = prefer the register-capped variant where it exists (RP 56, four row groups), 0 = 128-VGPR variants only
+// capped: 1 = prefer the register-capped variant where it exists (RP 56, four row groups), 0 = 128-VGPR variants only
 void launch_robust_polyfit(const float *z, const uint8_t *mask, int order, int iters, float c, int min_count, int min_mask_count, float *coef_out,
-                           float *resid_out, int B, int h, int w, hipStream_t st, int half_wg)
+                           float *resid_out, int B, int h, int w, hipStream_t st, int capped)
 {
     // i / w == umulhi(i, magic) for every i < h * w as long as h * w * w < 2^32
     const uint32_t magic = ((unsigned long long)h * w * w < 0x100000000ull) ? (uint32_t)(0x100000000ull / (unsigned)w) + 1u : 0u;
@@ -540,7 +537,7 @@ void launch_robust_polyfit(const float *z, const uint8_t *mask, int order, int i
     const int groups = cols_pad <= SEL_T ? std::min(SEL_T / cols_pad, h) : 0;
     const int need = groups ? (h + groups - 1) / groups : 1 << 30;
     if (need <= 64 && h + groups * 16 <= FIT_YTAB) {
-        if (half_wg == 1 && groups == 4 && need > 48 && need <= 56) VF_FIT_COL((k_robust_polyfit_col_w5<56, 4>), SEL_T, 4);
+        if (capped == 1 && groups == 4 && need > 48 && need <= 56) VF_FIT_COL((k_robust_polyfit_col_w5<56, 4>), SEL_T, 4);
         else if (groups == 4 && need > 32) {
             if (need <= 48) VF_FIT_COL((k_robust_polyfit_col<48, 4>), SEL_T, 4);
             else if (need <= 56) VF_FIT_COL((k_robust_polyfit_col<56, 4>), SEL_T, 4);

@@ -13,7 +13,7 @@ struct Tiers {
     int inpaint = 2;            // 2: frame-window march (k_telea_window) + whole-frame fallback; 1: whole-frame kernel only; 0: cluster front end first
     int flood = 2;              // 2: batched pops (k_unwrap_flood_batch / k_unwrap_flood_big); 1: one pop per step (k_unwrap_flood_hot); 0: frontier scan; 3: test only (test_hooks.h)
     int chamfer_twopass = 0;    // 1: force the one-wave two-pass chamfer even where the LDS closed form applies
-    int fit_half_wg = 1;        // 1: register-capped column polyfit (fits on a CU next to a march / flood wave); 0: 128-VGPR variant
+    int fit_capped = 1;        // 1: register-capped column polyfit (fits on a CU next to a march / flood wave); 0: 128-VGPR variant
     int telea_two_tier = 1;     // 1: 111 KB first tier of the window march + full-size retry of the frames it hands back; 0: full size only
 };
 
@@ -114,7 +114,7 @@ void launch_unwrap(const float *wrapped, const float *quality, const uint8_t *ma
 // ---- k_fit.hip --------------------------------------------------------------------------------
 // min_count: fitted (mask & finite) pixels needed (:1103); min_mask_count: mask pixels needed, NaN included (debug_ramp's own gate, :1364)
 void launch_robust_polyfit(const float *z, const uint8_t *mask, int order, int iters, float c, int min_count, int min_mask_count, float *coef_out,
-                           float *resid_out, int B, int h, int w, hipStream_t st, int half_wg = 1);
+                           float *resid_out, int B, int h, int w, hipStream_t st, int capped = 1);
 
 // ---- k_holes.hip (hole stage, shape_ftp.py:1153-1204, :1770-1801; live only when reliable_smooth_sigma_px == 0) ----------------------
 void launch_zeroed_keep_nan(const float *detr, const float *bg_med, const uint8_t *reliable, float *hmap, int B, int P, hipStream_t st);
