@@ -23,8 +23,6 @@ namespace vf {
 
 namespace {
 constexpr int BG_NW0 = 19200;                        // L0 words: 150 KB
-constexpr int BG_NW1 = (BG_NW0 + 63) / 64;           // 300
-constexpr int BG_NW2 = (BG_NW1 + 63) / 64;           // 5
 constexpr int BG_K = 8;                              // candidates per step
 
 __device__ inline uint32_t bg_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -35,12 +33,14 @@ __device__ inline int bg_top(unsigned long long v) { return 63 - __clzll((long l
 __global__ __launch_bounds__(64) void k_unwrap_flood_big(uint32_t *__restrict__ code_all, const int32_t *__restrict__ seed_in,
                                                          const int32_t *__restrict__ n_in, const uint32_t *__restrict__ inv_all, size_t inv_stride,
                                                          int32_t *__restrict__ ppar_all, size_t gstride, int32_t *__restrict__ need_generic, int max_ranks,
-                                                         int h, int w)
+                                                         int nw0, int h, int w, uint32_t magic)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    // nw0 words of L0 (sized by the host for the frame: every mask pixel can be a rank), then the two summary levels
+    const int nw1 = (nw0 + 63) >> 6, nw2 = (nw1 + 63) >> 6;
     unsigned long long *L0 = (unsigned long long *)lds_raw;
-    unsigned long long *L1 = L0 + BG_NW0;
-    unsigned long long *L2 = L1 + BG_NW1;
+    unsigned long long *L1 = L0 + nw0;
+    unsigned long long *L2 = L1 + nw1;
     const int lane = threadIdx.x;
     const size_t b = blockIdx.x;
     const int W2 = w + 2, EN = (h + 2) * W2;
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_big(uint32_t *__restrict__ 
     if (lane == 0) need_generic[b] = 0;
     if (seed < 0 || n <= 0) return;                                      // empty mask (shape_ftp.py:1047-1048)
     if (n > max_ranks) { if (lane == 0) need_generic[b] = 1; return; }       // mask larger than the bitmap: the generic kernel takes the frame
-    for (int i = lane; i < BG_NW0 + BG_NW1 + BG_NW2; i += 64) L0[i] = 0ull;
+    for (int i = lane; i < nw0 + nw1 + nw2; i += 64) L0[i] = 0ull;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __syncthreads();
     // the seed (rank n - 1) is the first frontier entry
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_big(uint32_t *__restrict__ 
     // every step commits at least candidate 0, so n steps are an upper bound (a guard, not a schedule)
     for (int step = 0; step < n; step++) {
         // ---- candidates: the top set bit of up to 8 consecutive non-empty L0 words under the top non-empty L1 word
-        const unsigned long long v2 = lane < BG_NW2 ? L2[lane] : 0ull;
+        const unsigned long long v2 = lane < nw2 ? L2[lane] : 0ull;
         const unsigned long long nz2 = __ballot(v2 != 0ull);
         if (nz2 == 0ull) break;                                          // frontier exhausted
         const int t2 = 63 - __clzll((long long)nz2);
@@ -114,7 +114,9 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_big(uint32_t *__restrict__ 
         int L;
         {
             const int pj = cpix, pi = (int)(uint32_t)__builtin_amdgcn_ds_bpermute(nb << 2, (int)mypix);
-            const int yj = pj / W2, xj = pj - yj * W2, yi = pi / W2, xi = pi - yi * W2;
+            // row = index / W2 as a multiply-high (exact while EN * W2 < 2^32; magic == 0: plain division)
+            const int yj = magic ? (int)__umulhi((uint32_t)pj, magic) : pj / W2, yi = magic ? (int)__umulhi((uint32_t)pi, magic) : pi / W2;
+            const int xj = pj - yj * W2, xi = pi - yi * W2;
             const bool close = live && nb < ci && abs(yj - yi) <= 2 && abs(xj - xi) <= 2;
             const unsigned long long cl = __ballot(close);
             L = C;
@@ -189,11 +191,17 @@ bool unwrap_big_supported(int h, int w)
 void launch_unwrap_flood_big(uint32_t *code, const int32_t *seed, const int32_t *n, const uint32_t *inv, size_t inv_stride, int32_t *ppar,
                              size_t gstride, int32_t *need_generic, bool force_generic, int B, int h, int w, hipStream_t st)
 {
-    const size_t lds = (size_t)(BG_NW0 + BG_NW1 + BG_NW2) * 8 + 64;
+    // the bitmap is sized for the frame (at most one rank per pixel), up to the 150 KB of BG_NW0 words: mid-size frames leave LDS to others
+    const long P = (long)h * w;
+    const unsigned long long EN = (unsigned long long)(h + 2) * (w + 2), W2 = (unsigned long long)w + 2;
+    const uint32_t magic = EN * W2 < 0x100000000ull ? (uint32_t)(0x100000000ull / W2) + 1u : 0u;
+    const int nw0 = (int)std::min<long>(BG_NW0, (P + 63) / 64);
+    const int nw1 = (nw0 + 63) / 64, nw2 = (nw1 + 63) / 64;
+    const size_t lds = (size_t)(nw0 + nw1 + nw2) * 8 + 64;
     static DynLdsOnce lds_once;
     ensure_dyn_lds(lds_once, (const void *)k_unwrap_flood_big, 160 * 1024);
     hipLaunchKernelGGL(k_unwrap_flood_big, dim3(B), dim3(64), lds, st, code, seed, n, inv, inv_stride, ppar, gstride, need_generic,
-                       force_generic ? 0 : BG_NW0 * 64, h, w);
+                       force_generic ? 0 : nw0 * 64, nw0, h, w, magic);
 }
 
 }  // namespace vf
