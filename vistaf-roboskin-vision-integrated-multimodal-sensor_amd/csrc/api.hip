@@ -213,28 +213,30 @@ void preprocess(vistaf_ftp_handle *hd, const void *frames, int format, int nfram
         if (src != hd->bad1) hipMemcpyAsync(hd->bad1, src, (size_t)B * P, hipMemcpyDeviceToDevice, st);
         launch_count_u8(hd->bad1, hd->bad_count, B, P, st);
         {
-            bool ev_done = false;
             int range = std::min(100, std::max(1, cv_round((double)c.bad_inpaint_radius)));   // cv::inpaint clamps the radius
             const uint8_t *seq_mask = hd->bad1;
             const int32_t *only = nullptr;
-            // default: the frame-window kernel (LDS-resident march), then the whole-frame kernel for the frames it hands back.
-            // Tiers::inpaint 0: first march every small independent cluster of hole pixels on its own window (pays off when
-            // the hole mask is many separate blobs; the fringe crests of this path form a few large clusters per frame, so it is off
-            // by default); 1: whole-frame kernel only
-            // Frames much larger than the window kernel's capacity (14 464 cells) -- the native 1182 x 1182 crops -- never fit one frame
-            // window; there the hole pixels fall into many independent clusters (the crests are ~60 px apart), so the cluster front
-            // end goes first on its own (measured at native size: march 1.95 s -> 0.54 s per batch).
+            // default (Tiers::inpaint 2): the frame-window kernel (LDS-resident march), then the whole-frame kernel for the frames it hands
+            // back; 1: whole-frame kernel only; 0: cluster by cluster -- every independent cluster of hole pixels on its own wave, in an LDS
+            // window when it fits, on the frame's global planes otherwise.  At 224 x 224 the hole pixels form ONE cluster per frame, so the
+            // frame window is the better tool; frames much larger than its capacity (14 464 cells) -- the native 1182 x 1182 crops -- never
+            // fit one window, and there the crests are ~60 px apart: many independent clusters (march at native size: 1.95 s per batch with
+            // the whole-frame kernel, 0.54 s with LDS clusters + whole-frame kernel for the rest, see DESIGN.md section 9 for the current figure).
             int mode = hd->tiers.inpaint;
             if (mode == 2 && (size_t)h * w > (size_t)8 * 14464) mode = 0;
             if (mode == 0 && inpaint_clusters_supported(range)) {
+                // every independent cluster of hole pixels on its own wave: LDS windows for those that fit, the frame's global planes for the rest
                 uint8_t *bad_big = nullptr;
-                launch_inpaint_clusters(hd->img, hd->bad1, range, hd->inpaint_cl_scratch, &bad_big, B, h, w, st);
-                seq_mask = bad_big;
+                ClusterPlanes left;
+                launch_inpaint_clusters(hd->img, hd->bad1, range, hd->inpaint_cl_scratch, &bad_big, &left, B, h, w, st);
+                if (timed) hipEventRecord(hd->ev[ST_INPAINT], st);      // (after the LDS cluster pass: its bookkeeping counts as mask work)
+                launch_inpaint_big_clusters(hd->img, bad_big, range, hd->inpaint_scratch, hd->status, left, B, h, w, st);
+            } else {
+                if (timed && mode == 1) hipEventRecord(hd->ev[ST_INPAINT], st);
+                if (mode != 1) only = launch_inpaint_window(hd->img, seq_mask, range, hd->inpaint_win_scratch, B, h, w, st, timed ? hd->ev[ST_INPAINT] : nullptr,
+                                                               hd->tiers.telea_two_tier != 0);
+                launch_inpaint_telea(hd->img, seq_mask, range, hd->inpaint_scratch, hd->status, only, B, h, w, st);
             }
-            if (timed && mode != 2) { hipEventRecord(hd->ev[ST_INPAINT], st); ev_done = true; }      // (after the cluster pass: its bookkeeping counts as mask work)
-            if (mode != 1) only = launch_inpaint_window(hd->img, seq_mask, range, hd->inpaint_win_scratch, B, h, w, st, (timed && !ev_done) ? hd->ev[ST_INPAINT] : nullptr,
-                                                           hd->tiers.telea_two_tier != 0);
-            launch_inpaint_telea(hd->img, seq_mask, range, hd->inpaint_scratch, hd->status, only, B, h, w, st);
         }
     } else if (timed) hipEventRecord(hd->ev[ST_INPAINT], st);
     if (timed) hipEventRecord(hd->ev[ST_PREPROC], st);

@@ -173,57 +173,41 @@ __global__ void k_telea_prep(const uint8_t *__restrict__ bad_all, uint8_t *__res
     if (in) atomicAdd(&nbad_all[b], 1);
 }
 
+// Window of a march in padded coordinates (inclusive) and the cluster it is restricted to: lab == nullptr marches every hole pixel of the
+// frame (the window is then the whole padded frame); otherwise only cells whose label (component of the dilated hole mask, k_inpaint_cl.hip)
+// equals `root` belong to this march -- other clusters may reach into the bounding window, their cells are simply skipped by the scans, and
+// the march itself never leaves its own cluster (rings of different clusters are at least three cells apart).
+struct TeleaScan { int i0, i1, j0, j1; const int32_t *lab; int root; };
+
 template <bool LF>
-__global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const uint8_t *__restrict__ bad_all, int range,
-                                              uint8_t *gflags, float *gT, uint32_t *gqueue, const int32_t *__restrict__ nbad_all, int32_t *status, int h,
-                                              int w)
+__device__ __attribute__((always_inline)) inline void telea_march_global(float *img, int range, uint8_t *f, uint8_t *fo, float *t, TQueue &q,
+                                                                         const TeleaScan sc, int h, int w, int lane, size_t b)
 {
-    extern __shared__ unsigned char lds_raw[];
-    const int lane = threadIdx.x;
-    const size_t b = blockIdx.x;
-    const int er = h + 2, ec = w + 2, en = er * ec, P = h * w;
-    float *img = img_all + b * (size_t)P;
-    const uint8_t *bad = bad_all + b * (size_t)P;
-    float *t = gT + b * (size_t)en;
-    TQueue q;
-    if (LF) { q.T = (uint32_t *)lds_raw; q.idx = (uint32_t *)(lds_raw + (size_t)TQ_CAP * 4); q.cap = TQ_CAP; }
-    else { q.T = gqueue + b * (size_t)en * 2; q.idx = q.T + en; q.cap = en; }   // large frames: queue in global memory
-    q.head = q.tail = 0; q.overflow = 0;
-    uint8_t *f, *fo;
-    if (LF) { f = lds_raw + (size_t)TQ_CAP * 8; fo = f + ((en + 15) & ~15); }
-    else { f = gflags + b * (size_t)en * 2; fo = f + en; }
-
-    TSTAMP(0);
-    TSTAMP(0);
-    // ---- flags and the initial T field were prepared by k_telea_prep (all CUs); stage the flag planes into LDS
-    const int nbad = nbad_all[b];
-    if (nbad == 0) return;
-    if (LF) {
-        const uint8_t *gsrc = gflags + b * (size_t)en * 2;
-        for (int i = lane; i < en; i += 64) { f[i] = gsrc[i]; fo[i] = gsrc[en + i]; }
-        __syncthreads();
-    }
-
+    const int er = h + 2, ec = w + 2;
+    // raster scan of the window, 64 columns at a time: the cells of this march that satisfy `pred`
+    auto mine = [&](int row, int col) -> bool { return sc.lab == nullptr || (row >= 1 && row <= h && col >= 1 && col <= w && sc.lab[(size_t)(row - 1) * w + (col - 1)] == sc.root); };
     TSTAMP(1);
     unsigned long long npop1 = 0, npop2 = 0;
     // ---- pass 1: outside T field.  Seeds (band, T = 0) pop first, in raster order.
     for (int phase = 0; phase < 2; phase++) {
         if (phase == 1) TSTAMP(2);
-        int base = 0;
+        int base = 0, row = sc.i0, cb = sc.j0;
         unsigned long long pend = 0;
         for (;;) {
             int p;
             if (phase == 0) {
-                while (!pend && base < en) {
-                    int i = base + lane;
-                    pend = __ballot(i < en && (ldf<LF>(fo, i) & T_SEED));
-                    if (!pend) base += 64;
+                while (!pend && row <= sc.i1) {
+                    const int col = cb + lane;
+                    const int i = row * ec + col;
+                    pend = __ballot(col <= sc.j1 && (ldf<LF>(fo, i) & T_SEED) && mine(row, col));
+                    base = row * ec + cb;
+                    cb += 64;
+                    if (cb > sc.j1) { cb = sc.j0; row++; }
                 }
                 if (!pend) break;
                 int l = __ffsll((long long)pend) - 1;
                 pend &= pend - 1;
                 p = base + l;
-                if (!pend) base += 64;
             } else {
                 p = tq_pop<LF>(q, lane);
                 if (p < 0) break;
@@ -265,8 +249,11 @@ __global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const
     __syncthreads();
     TSTAMP(3);
     // negate T where the outside pass ran (CHANGE), seeds keep T = 0
-    for (int i = lane; i < en; i += 64)
-        if ((ldf<LF>(fo, i) & 0x7f) == T_CHANGE) { float v = ldc(t + i); t[i] = -v; }
+    for (int row = sc.i0; row <= sc.i1; row++)
+        for (int col = sc.j0 + lane; col <= sc.j1; col += 64) {
+            const int i = row * ec + col;
+            if ((ldf<LF>(fo, i) & 0x7f) == T_CHANGE && mine(row, col)) { float v = ldc(t + i); t[i] = -v; }
+        }
     drain();
     __syncthreads();
 
@@ -285,21 +272,23 @@ __global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const
     const int side = 2 * range + 1, nn = side * side;
     for (int phase = 0; phase < 2; phase++) {
         if (phase == 1) TSTAMP(5);
-        int base = 0;
+        int base = 0, row = sc.i0, cb = sc.j0;
         unsigned long long pend = 0;
         for (;;) {
             int p;
             if (phase == 0) {
-                while (!pend && base < en) {
-                    int i = base + lane;
-                    pend = __ballot(i < en && (ldf<LF>(fo, i) & T_SEED));
-                    if (!pend) base += 64;
+                while (!pend && row <= sc.i1) {
+                    const int col = cb + lane;
+                    const int i = row * ec + col;
+                    pend = __ballot(col <= sc.j1 && (ldf<LF>(fo, i) & T_SEED) && mine(row, col));
+                    base = row * ec + cb;
+                    cb += 64;
+                    if (cb > sc.j1) { cb = sc.j0; row++; }
                 }
                 if (!pend) break;
                 int l = __ffsll((long long)pend) - 1;
                 pend &= pend - 1;
                 p = base + l;
-                if (!pend) base += 64;
             } else {
                 p = tq_pop<LF>(q, lane);
                 if (p < 0) break;
@@ -378,10 +367,75 @@ __global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const
     }
     TSTAMP(6);
 #ifdef VISTAF_DEBUG
-    if (b == 0 && lane == 0) { g_telea_dbg[8] = npop1; g_telea_dbg[9] = npop2; g_telea_dbg[10] = (unsigned long long)nbad; }
+    if (b == 0 && lane == 0) { g_telea_dbg[8] = npop1; g_telea_dbg[9] = npop2; }
 #endif
-    if (q.overflow && lane == 0) status[b] = 2;
+    (void)npop1; (void)npop2;
 }
+
+template <bool LF>
+__global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const uint8_t *__restrict__ bad_all, int range,
+                                              uint8_t *gflags, float *gT, uint32_t *gqueue, const int32_t *__restrict__ nbad_all, int32_t *status, int h,
+                                              int w)
+{
+    extern __shared__ unsigned char lds_raw[];
+    const int lane = threadIdx.x;
+    const size_t b = blockIdx.x;
+    const int er = h + 2, ec = w + 2, en = er * ec, P = h * w;
+    float *img = img_all + b * (size_t)P;
+    float *t = gT + b * (size_t)en;
+    TQueue q;
+    if (LF) { q.T = (uint32_t *)lds_raw; q.idx = (uint32_t *)(lds_raw + (size_t)TQ_CAP * 4); q.cap = TQ_CAP; }
+    else { q.T = gqueue + b * (size_t)en * 2; q.idx = q.T + en; q.cap = en; }   // large frames: queue in global memory
+    q.head = q.tail = 0; q.overflow = 0;
+    uint8_t *f, *fo;
+    if (LF) { f = lds_raw + (size_t)TQ_CAP * 8; fo = f + ((en + 15) & ~15); }
+    else { f = gflags + b * (size_t)en * 2; fo = f + en; }
+    TSTAMP(0);
+    // ---- flags and the initial T field were prepared by k_telea_prep (all CUs); stage the flag planes into LDS
+    if (nbad_all[b] == 0) return;
+    if (LF) {
+        const uint8_t *gsrc = gflags + b * (size_t)en * 2;
+        for (int i = lane; i < en; i += 64) { f[i] = gsrc[i]; fo[i] = gsrc[en + i]; }
+        __syncthreads();
+    }
+    const TeleaScan sc = {0, er - 1, 0, ec - 1, nullptr, 0};
+    telea_march_global<LF>(img, range, f, fo, t, q, sc, h, w, lane, b);
+    if (q.overflow && lane == 0) status[b] = 2;
+    (void)bad_all;
+}
+
+// The clusters the LDS windows could not take (k_inpaint_cl.hip: `list` of roots per frame), each on its own wave: blockIdx.x walks the list,
+// blockIdx.y is the frame.  Flags, T and the image are the frame's planes in global memory -- clusters touch disjoint cells --, every slot
+// has its own slice of the frame's queue arrays.  The pop order inside a cluster is the whole-frame queue's (k_inpaint_cl.hip).
+__global__ __launch_bounds__(64) void k_telea_big_clusters(float *__restrict__ img_all, int range, uint8_t *gflags, float *gT, uint32_t *gqueue,
+                                                           const int32_t *__restrict__ labels_all, const int32_t *__restrict__ list_all,
+                                                           const int32_t *__restrict__ count, const int32_t *__restrict__ xmin,
+                                                           const int32_t *__restrict__ ymin, const int32_t *__restrict__ xmax,
+                                                           const int32_t *__restrict__ ymax, int32_t *status, int h, int w)
+{
+    const int lane = threadIdx.x;
+    const size_t b = blockIdx.y;
+    const int er = h + 2, ec = w + 2, en = er * ec, P = h * w;
+    const int ncl = count[b];
+    const int M = range + 1;
+    const int slot_cap = (int)((size_t)en / gridDim.x) & ~63;
+    for (int c = blockIdx.x; c < ncl; c += gridDim.x) {
+        const int rootp = list_all[b * (size_t)P + c];
+        const size_t root = b * (size_t)P + rootp;
+        TQueue q;
+        q.T = gqueue + b * (size_t)en * 2 + (size_t)blockIdx.x * slot_cap;
+        q.idx = q.T + en;
+        q.cap = slot_cap;
+        q.head = q.tail = 0; q.overflow = 0;
+        // bounding box of the cluster's hole pixels (image coordinates) grown by range + 1, in padded coordinates, clipped to the padded frame
+        const TeleaScan sc = {max(0, ymin[root] + 1 - M), min(er - 1, ymax[root] + 1 + M), max(0, xmin[root] + 1 - M), min(ec - 1, xmax[root] + 1 + M),
+                              labels_all + b * (size_t)P, rootp};
+        uint8_t *f = gflags + b * (size_t)en * 2;
+        telea_march_global<false>(img_all + b * (size_t)P, range, f, f + en, gT + b * (size_t)en, q, sc, h, w, lane, b);
+        if (q.overflow && lane == 0) status[b] = 2;
+    }
+}
+
 
 #ifdef VISTAF_DEBUG
 void telea_debug_dump()
@@ -424,6 +478,24 @@ void launch_inpaint_telea(float *img, const uint8_t *bad, int range, void *scrat
     } else {
         hipLaunchKernelGGL(k_telea<false>, dim3(B), dim3(64), 0, st, img, bad, range, gflags, gT, gqueue, nbad, status, h, w);
     }
+}
+
+// The hole pixels of `bad_big` (clusters too large for an LDS window), one wave per cluster, up to 32 waves per frame: same scratch layout as
+// launch_inpaint_telea (flags, T and the queue arrays, which are cut into one slice per wave).
+void launch_inpaint_big_clusters(float *img, const uint8_t *bad_big, int range, void *scratch, int32_t *status, const ClusterPlanes &left, int B, int h,
+                                 int w, hipStream_t st)
+{
+    size_t en = (size_t)(h + 2) * (w + 2);
+    float *gT = (float *)scratch;
+    uint8_t *gflags = (uint8_t *)scratch + (size_t)B * en * sizeof(float);
+    uint32_t *gqueue = (uint32_t *)((((uintptr_t)scratch + (size_t)B * en * sizeof(float) + (size_t)B * en * 2) + 255) & ~(uintptr_t)255);
+    int32_t *nbad = (int32_t *)(gqueue + (size_t)B * en * 2);
+    hipMemsetAsync(nbad, 0, sizeof(int32_t) * B, st);
+    hipLaunchKernelGGL(k_telea_prep, dim3((unsigned)((en + 255) / 256), B), dim3(256), 0, st, bad_big, gflags, gT, nbad, (const int32_t *)nullptr, range, h, w);
+    // waves per frame = slices of the frame's queue arrays: at least 8192 entries each, 4..32 of them
+    const int nslot = (int)std::min<size_t>(32, std::max<size_t>(4, en / 8192));
+    hipLaunchKernelGGL(k_telea_big_clusters, dim3(nslot, B), dim3(64), 0, st, img, range, gflags, gT, gqueue, left.labels, left.list, left.count, left.xmin,
+                       left.ymin, left.xmax, left.ymax, status, h, w);
 }
 
 }  // namespace vf

@@ -49,6 +49,20 @@ __global__ void k_cluster_list(const int32_t *__restrict__ labels, const int32_t
     else { int k = atomicAdd(&count[b], 1); list[b * (size_t)P + k] = p; }
 }
 
+// after the LDS march: the roots still flagged `big` (window too large, or the queue of their window overflowed), compacted into `list`
+__global__ void k_cluster_list_big(const int32_t *__restrict__ labels, const int32_t *__restrict__ xmin, const uint8_t *__restrict__ big,
+                                   int32_t *__restrict__ list, int32_t *__restrict__ count, int h, int w)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    size_t b = blockIdx.y;
+    int P = h * w;
+    if (p >= P) return;
+    size_t i = b * (size_t)P + p;
+    if (labels[i] != p || xmin[i] == 0x7f7f7f7f || !big[i]) return;
+    int k = atomicAdd(&count[b], 1);
+    list[b * (size_t)P + k] = p;
+}
+
 // bad_big = bad & big[root]
 __global__ void k_split_bad(const uint8_t *__restrict__ bad, const int32_t *__restrict__ labels, const uint8_t *__restrict__ big,
                             uint8_t *__restrict__ bad_big, int P)
@@ -73,8 +87,9 @@ int inpaint_cluster_cells_cap();
 void launch_telea_clusters2(float *img, const uint8_t *bad, const int32_t *labels, const int32_t *list, const int32_t *count, const int32_t *xmin,
                             const int32_t *ymin, const int32_t *xmax, const int32_t *ymax, uint8_t *big, int range, int B, int h, int w, hipStream_t st);
 
-// Marches every cluster that fits on its own window; *bad_big_out = hole mask of the clusters that were left over.
-void launch_inpaint_clusters(float *img, const uint8_t *bad, int range, void *scratch, uint8_t **bad_big_out, int B, int h, int w,
+// Marches every cluster that fits on its own window; *bad_big_out = hole mask of the clusters that were left over, *left = their roots
+// (list / count per frame, in no particular order), labels and bounding boxes for launch_inpaint_big_clusters.
+void launch_inpaint_clusters(float *img, const uint8_t *bad, int range, void *scratch, uint8_t **bad_big_out, ClusterPlanes *left, int B, int h, int w,
                              hipStream_t st)
 {
     const int P = h * w;
@@ -105,6 +120,12 @@ void launch_inpaint_clusters(float *img, const uint8_t *bad, int range, void *sc
     launch_telea_clusters2(img, bad, labels, list, count, xmin, ymin, xmax, ymax, big, range, B, h, w, st);
     hipLaunchKernelGGL(k_split_bad, g, dim3(256), 0, st, bad, labels, big, bad_big, P);
     *bad_big_out = bad_big;
+    if (left) {
+        // the list of the clusters marched above is dead: it now takes the roots that are left
+        (void)hipMemsetAsync(count, 0, (size_t)B * 4, st);
+        hipLaunchKernelGGL(k_cluster_list_big, g, dim3(256), 0, st, labels, xmin, big, list, count, h, w);
+        left->labels = labels; left->list = list; left->count = count; left->xmin = xmin; left->ymin = ymin; left->xmax = xmax; left->ymax = ymax;
+    }
 }
 
 }  // namespace vf
