@@ -72,19 +72,22 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_big(uint32_t *__restrict__ 
         const int l = nb < 4 ? nb : nb + 1;                              // the 3 x 3 block without its centre, lexicographic (dy, dx)
         doff = (l / 3 - 1) * W2 + (l % 3 - 1);
     }
-    // every step commits at least candidate 0, so n steps are an upper bound (a guard, not a schedule)
-    for (int step = 0; step < n; step++) {
-        // ---- candidates: the top set bit of up to 8 consecutive non-empty L0 words under the top non-empty L1 word
+    // Candidates of a step: the top set bit of up to 8 consecutive non-empty L0 words under the top non-empty L1 word (three dependent LDS
+    // rounds), and the read of their pixels from the sorted-index array.  It runs at the END of a step, before the fence that drains the
+    // step's stores: the bitmap is final by then, and the index read overlaps the drain.
+    int C = 0, myw0 = -1, myrank = -1;
+    uint32_t mypix = 0;
+    auto search = [&]() {
+        C = 0; myw0 = -1; myrank = -1; mypix = 0;
         const unsigned long long v2 = lane < nw2 ? L2[lane] : 0ull;
         const unsigned long long nz2 = __ballot(v2 != 0ull);
-        if (nz2 == 0ull) break;                                          // frontier exhausted
+        if (nz2 == 0ull) return;                                         // frontier exhausted: C = 0
         const int t2 = 63 - __clzll((long long)nz2);
         const unsigned long long top2 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(v2 >> 32), t2) << 32) |
                                         (uint32_t)__builtin_amdgcn_readlane((int)v2, t2);
         const int w1 = t2 * 64 + bg_top(top2);
         unsigned long long v1 = L1[w1];                                  // uniform, non-zero
         // lane k < 8 takes the k-th highest set bit of v1
-        int myw0 = -1;
         {
             unsigned long long t = v1;
             for (int k = 0; k < BG_K; k++) {
@@ -98,11 +101,14 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_big(uint32_t *__restrict__ 
         const int have = (int)__popcll(__ballot(lane < BG_K && myw0 >= 0));
         // rule (iii): the list ends after the first word with more than one frontier rank
         const unsigned long long multi = __ballot(lane < BG_K && myw0 >= 0 && __popcll(v0) > 1);
-        int C = have;
+        C = have;
         if (multi) C = min(C, __ffsll((long long)multi));
-        const int myrank = (lane < C) ? myw0 * 64 + bg_top(v0) : -1;     // lanes 0..C-1: candidate ranks, descending
-        uint32_t mypix = 0;
+        myrank = (lane < C) ? myw0 * 64 + bg_top(v0) : -1;               // lanes 0..C-1: candidate ranks, descending
         if (lane < C) mypix = inv[myrank];
+    };
+    search();
+    // every step commits at least candidate 0, so n steps are an upper bound (a guard, not a schedule)
+    for (int step = 0; step < n && C > 0; step++) {
         // ---- one global round trip: the 8 neighbour codes of every candidate
         const int cpix = (int)(uint32_t)__builtin_amdgcn_ds_bpermute(ci << 2, (int)mypix);
         const bool live = ci < C;
@@ -176,6 +182,8 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_big(uint32_t *__restrict__ 
             atomicOr(&L1[r >> 12], 1ull << ((r >> 6) & 63));
             atomicOr(&L2[r >> 18], 1ull << ((r >> 12) & 63));
         }
+        __builtin_amdgcn_wave_barrier();
+        search();                                                        // next step's candidates; its index read overlaps the drain below
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         __builtin_amdgcn_wave_barrier();
     }
