@@ -7,16 +7,16 @@
 //     GLOBAL memory -- 5.6 MB per native frame;
 //   * the priority queue is a three-level bitmap over the ranks in LDS: 19 200 words = 1.23 M ranks (the ROI disc of a native crop holds
 //     1.09 M pixels), one summary bit per word on the two levels above.  Push = three LDS ORs, pop = three dependent LDS reads;
-//   * one wave per frame, up to 8 pops per step as in k_unwrap_flood_batch: the candidates are the top set bits (one per L0 word, lanes
-//     0..7 read their words together), their pixels come from the sorted-index array of the rank kernel, lane = candidate * 8 + neighbour
+//   * one wave per frame, up to 8 pops per step as in k_unwrap_flood_batch: the candidates are the 8 highest set bits of the up to 8 highest
+//     non-empty words under the top summary word (lanes 0..7 read their words together), their pixels come from the sorted-index array of the rank kernel, lane = candidate * 8 + neighbour
 //     loads the 8 neighbour codes in ONE global round trip, and the longest prefix that provably pops in that order with the same
 //     neighbour states as the one-at-a-time loop is committed:
 //       (i)  a candidate within Chebyshev distance 2 of an earlier candidate ends the prefix before it (it could see the earlier one as a
 //            visited neighbour or share a fresh neighbour with it);
-//       (ii) a fresh neighbour that outranks a later candidate has to pop before it: the prefix ends before that candidate;
-//       (iii) an L0 word with more than one frontier rank ends the candidate list after its top bit (its second bit is the true next pop).
+//       (ii) a fresh neighbour that outranks a later candidate has to pop before it: the prefix ends before that candidate.
 //   A step costs two dependent global round trips (sorted index -> pixel, pixel -> neighbour codes) instead of a scan of the whole
 //   frontier array per pop (k_unwrap_flood<false>, which stays the fallback for masks of more than 1.23 M pixels).
+#include <cstdio>
 #include "kernels.hpp"
 
 namespace vf {
@@ -28,6 +28,16 @@ constexpr int BG_K = 8;                              // candidates per step
 __device__ inline uint32_t bg_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline void bg_st(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline int bg_top(unsigned long long v) { return 63 - __clzll((long long)v); }
+__device__ inline unsigned long long bg_lane64(unsigned long long v, int l)
+{
+    return ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+}
+#ifdef VISTAF_DEBUG
+__device__ unsigned long long g_big_dbg[8];        // frame 0: steps, candidates, commits, steps cut by rule (i) / (ii) / (iii)
+#define BG_COUNT(i, v) do { if (b == 0 && lane == 0) g_big_dbg[i] += (unsigned long long)(v); } while (0)
+#else
+#define BG_COUNT(i, v) do { } while (0)
+#endif
 }  // namespace
 
 __global__ __launch_bounds__(64) void k_unwrap_flood_big(uint32_t *__restrict__ code_all, const int32_t *__restrict__ seed_in,
@@ -75,10 +85,10 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_big(uint32_t *__restrict__ 
     // Candidates of a step: the top set bit of up to 8 consecutive non-empty L0 words under the top non-empty L1 word (three dependent LDS
     // rounds), and the read of their pixels from the sorted-index array.  It runs at the END of a step, before the fence that drains the
     // step's stores: the bitmap is final by then, and the index read overlaps the drain.
-    int C = 0, myw0 = -1, myrank = -1;
+    int C = 0, myw0 = -1, mywd = -1, myrank = -1;        // mywd: the L0 word of this lane's candidate
     uint32_t mypix = 0;
     auto search = [&]() {
-        C = 0; myw0 = -1; myrank = -1; mypix = 0;
+        C = 0; myw0 = -1; mywd = -1; myrank = -1; mypix = 0;
         const unsigned long long v2 = lane < nw2 ? L2[lane] : 0ull;
         const unsigned long long nz2 = __ballot(v2 != 0ull);
         if (nz2 == 0ull) return;                                         // frontier exhausted: C = 0
@@ -99,11 +109,23 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_big(uint32_t *__restrict__ 
         }
         const unsigned long long v0 = (lane < BG_K && myw0 >= 0) ? L0[myw0] : 0ull;
         const int have = (int)__popcll(__ballot(lane < BG_K && myw0 >= 0));
-        // rule (iii): the list ends after the first word with more than one frontier rank
-        const unsigned long long multi = __ballot(lane < BG_K && myw0 >= 0 && __popcll(v0) > 1);
-        C = have;
-        if (multi) C = min(C, __ffsll((long long)multi));
-        myrank = (lane < C) ? myw0 * 64 + bg_top(v0) : -1;               // lanes 0..C-1: candidate ranks, descending
+        // the 8 highest frontier ranks: the words in descending order, the bits of a word in descending order (in smooth quality maps the top
+        // of the frontier is a run of neighbouring ranks, i.e. several bits of ONE word)
+        {
+            int cnt = 0;
+            for (int j = 0; j < have && cnt < BG_K; j++) {
+                unsigned long long t = bg_lane64(v0, j);
+                const int w0j = __builtin_amdgcn_readlane(myw0, j);
+                while (t != 0ull && cnt < BG_K) {
+                    const int bt = bg_top(t);
+                    if (lane == cnt) { myrank = w0j * 64 + bt; mywd = w0j; }
+                    t &= ~(1ull << bt);
+                    cnt++;
+                }
+            }
+            C = cnt;
+        }
+        BG_COUNT(6, have);
         if (lane < C) mypix = inv[myrank];
     };
     search();
@@ -127,6 +149,7 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_big(uint32_t *__restrict__ 
             const unsigned long long cl = __ballot(close);
             L = C;
             if (cl) L = min(L, (int)((__ffsll((long long)cl) - 1) >> 3));
+            BG_COUNT(3, L < C);
         }
         // (ii) a fresh neighbour of candidate i that outranks a LATER candidate k has to pop before k (and whatever it pushes in turn could
         // touch k's neighbourhood): the prefix ends before the first such k.  Candidate ranks descend, so k0 = the first k > i below it.
@@ -142,9 +165,10 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_big(uint32_t *__restrict__ 
 #pragma unroll
             for (int k = 1; k < BG_K; k++) {
                 if (k >= L) break;
-                if (__ballot(k0 <= k)) { L = k; break; }
+                if (__ballot(k0 <= k)) { L = k; BG_COUNT(4, 1); break; }
             }
         }
+        BG_COUNT(0, 1); BG_COUNT(1, C); BG_COUNT(2, L);
         // ---- commit candidates 0..L-1
         const bool com = ci < L;
         const unsigned long long vis = __ballot(com && cd == 1u);
@@ -163,14 +187,14 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_big(uint32_t *__restrict__ 
                 bg_st(code + cpix, 1u);
             }
         }
-        // clear the committed candidates' bits (one L0 word each; L1 / L2 summaries when a word empties)
+        // clear the committed candidates' bits (several may share an L0 word: the atomic that empties it clears the summaries)
         if (lane < L) {
             const unsigned long long bit = 1ull << (myrank & 63);
-            const unsigned long long old = atomicAnd(&L0[myw0], ~bit);
+            const unsigned long long old = atomicAnd(&L0[mywd], ~bit);
             if ((old & ~bit) == 0ull) {
-                const unsigned long long b1 = 1ull << (myw0 & 63);
-                const unsigned long long o1 = atomicAnd(&L1[myw0 >> 6], ~b1);
-                if ((o1 & ~b1) == 0ull) atomicAnd(&L2[myw0 >> 12], ~(1ull << ((myw0 >> 6) & 63)));
+                const unsigned long long b1 = 1ull << (mywd & 63);
+                const unsigned long long o1 = atomicAnd(&L1[mywd >> 6], ~b1);
+                if ((o1 & ~b1) == 0ull) atomicAnd(&L2[mywd >> 12], ~(1ull << ((mywd >> 6) & 63)));
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -188,6 +212,16 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_big(uint32_t *__restrict__ 
         __builtin_amdgcn_wave_barrier();
     }
 }
+
+#ifdef VISTAF_DEBUG
+void unwrap_big_debug_dump()
+{
+    unsigned long long h[8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_big_dbg), sizeof(h)) != hipSuccess) return;
+    printf("[flood big dbg] frame 0, all calls: steps %llu | candidates %llu (words found %llu) | commits %llu | steps cut by (i) %llu (ii) %llu (iii) %llu\n", h[0], h[1],
+           h[6], h[2], h[3], h[4], h[5]);
+}
+#endif
 
 bool unwrap_big_supported(int h, int w)
 {
