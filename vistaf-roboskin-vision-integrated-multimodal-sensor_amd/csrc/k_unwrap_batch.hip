@@ -14,12 +14,19 @@
 //        prefix ends with the candidate that produced it and the entry goes into HOT.
 // Everything else about a pop (parent = lexicographically smallest visited neighbour, fresh neighbours to the
 // frontier) touches only the candidate's own 3x3 block, so the committed pops are independent.
+#include <cstdio>
 #include "kernels.hpp"
 
 namespace vf {
 
 constexpr int BT_NW = 1024;    // 64-bit words of the cold bitmap (codes < 65536)
 constexpr int BT_K = 8;        // candidates per step
+#ifdef VISTAF_DEBUG
+__device__ unsigned long long g_batch_dbg[8];      // frame 0: steps, candidates, commits, steps cut by (i) / (ii), refills, HOT inserts
+#define BT_COUNT(i, v) do { if (b == 0 && lane == 0) g_batch_dbg[i] += (unsigned long long)(v); } while (0)
+#else
+#define BT_COUNT(i, v) do { } while (0)
+#endif
 
 __device__ inline uint32_t bt_shr1(uint32_t v, uint32_t fill) { return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xf, 0xf, false); }
 __device__ inline uint32_t bt_bperm(uint32_t v, int src_lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v); }
@@ -91,6 +98,7 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_batch(const uint16_t *__res
     for (;;) {
         // ---- refill: HOT holds fewer than K entries: append the top cold codes (already in descending order)
         if (H < BT_K && cold_any) {
+            BT_COUNT(5, 1);
             unsigned long long l1 = lane < 16 ? L1[lane] : 0ull;
             unsigned long long nz = __ballot(l1 != 0ull);
             if (nz == 0ull) cold_any = false;
@@ -175,8 +183,9 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_batch(const uint16_t *__res
         const unsigned long long cmC = __ballot(conflict);
         const unsigned long long cmH = __ballot(e > clast);
         int m = mav;
-        if (cmC) { int g = (__ffsll((long long)cmC) - 1) >> 3; m = g < m ? g : m; }
-        if (cmH) { int g = ((__ffsll((long long)cmH) - 1) >> 3) + 1; m = g < m ? g : m; }
+        if (cmC) { int g = (__ffsll((long long)cmC) - 1) >> 3; m = g < m ? g : m; BT_COUNT(3, g < mav); }
+        if (cmH) { int g = ((__ffsll((long long)cmH) - 1) >> 3) + 1; BT_COUNT(4, g < m); m = g < m ? g : m; }
+        BT_COUNT(0, 1); BT_COUNT(1, mav); BT_COUNT(2, m);
 
         // ---- commit candidates 0..m-1
         const bool act = ci < m;
@@ -233,6 +242,15 @@ __global__ __launch_bounds__(64) void k_unwrap_flood_batch(const uint16_t *__res
     }
     if (lane == 0) order[ostride - 1] = (uint32_t)npop;
 }
+
+#ifdef VISTAF_DEBUG
+void unwrap_batch_debug_dump()
+{
+    unsigned long long h[8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_batch_dbg), sizeof(h)) != hipSuccess) return;
+    printf("[flood batch dbg] frame 0, all calls: steps %llu | candidates %llu | commits %llu | steps cut by (i) %llu (ii) %llu | refills %llu\n", h[0], h[1], h[2], h[3], h[4], h[5]);
+}
+#endif
 
 // k_unwrap_replay: integer wrap counts along the growth tree (shape_ftp.py:1060-1076) by replaying the pops in order.
 // A pixel's count is its parent's plus the wrap of the phase step between them, and a parent always pops before
