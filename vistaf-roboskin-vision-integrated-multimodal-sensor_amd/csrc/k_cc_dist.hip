@@ -54,12 +54,27 @@ __device__ inline void cc_unite(int32_t *L, int a, int b)
 // Connected components (8-neighbourhood) by atomic union-find in global memory for frames too large for the LDS forest below: init, merge and
 // flatten as separate launches over all pixels of the batch (one 1024-thread workgroup per frame took 45 ms per call on native 1182 x 1182 crops).  The union is an atomic "hang the larger root under the smaller" at agent scope,
 // so the result -- every pixel labelled with the smallest pixel index of its component -- does not depend on which workgroup unites what when.
-__global__ void k_cc_init(const uint8_t *__restrict__ mask, int32_t *__restrict__ labels, int P)
+// init: every mask pixel points at the start of its horizontal run INSIDE its wave's 64-pixel segment (one ballot: a chain of "unite with the left
+// neighbour" along a 1000-pixel run is a 1000-hop walk for every later find); merge then links a run to its left neighbour only where it
+// crosses a segment boundary, and to the row above
+__global__ void k_cc_init(const uint8_t *__restrict__ mask, int32_t *__restrict__ labels, int P, int w)
 {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    size_t b = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const bool in = p < P && mask[b * (size_t)P + (p < P ? p : 0)] != 0;
+    const int x = p % w;
+    const unsigned long long bits = __ballot(in);
+    const unsigned long long rowstart = __ballot(x == 0);
+    // lane j starts a run: masked, and lane j - 1 is not masked, or j is the first pixel of a row, or j == 0
+    const unsigned long long starts = bits & (~(bits << 1) | rowstart | 1ull);
     if (p >= P) return;
-    labels[b * (size_t)P + p] = mask[b * (size_t)P + p] ? p : -1;
+    int lab = -1;
+    if (in) {
+        const unsigned long long upto = starts & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+        lab = p - lane + (63 - __clzll((long long)upto));
+    }
+    labels[b * (size_t)P + p] = lab;
 }
 __global__ void k_cc_merge(const uint8_t *__restrict__ mask, int32_t *__restrict__ labels, int h, int w)
 {
@@ -71,7 +86,7 @@ __global__ void k_cc_merge(const uint8_t *__restrict__ mask, int32_t *__restrict
     int32_t *L = labels + b * (size_t)P;
     if (!m[p]) return;
     int y = p / w, x = p - y * w;
-    if (x > 0 && m[p - 1]) cc_unite(L, p, p - 1);
+    if ((threadIdx.x & 63) == 0 && x > 0 && m[p - 1]) cc_unite(L, p, p - 1);       // the run continues in the previous segment
     if (y > 0) {
         if (m[p - w]) cc_unite(L, p, p - w);
         if (x > 0 && m[p - w - 1]) cc_unite(L, p, p - w - 1);
@@ -205,7 +220,7 @@ void launch_cc_label(const uint8_t *mask, int32_t *labels, int B, int h, int w, 
         return;
     }
     const dim3 g((P + 255) / 256, B);
-    hipLaunchKernelGGL(k_cc_init, g, dim3(256), 0, st, mask, labels, P);
+    hipLaunchKernelGGL(k_cc_init, g, dim3(256), 0, st, mask, labels, P, w);
     hipLaunchKernelGGL(k_cc_merge, g, dim3(256), 0, st, mask, labels, h, w);
     hipLaunchKernelGGL(k_cc_flatten, g, dim3(256), 0, st, mask, labels, P);
 }
