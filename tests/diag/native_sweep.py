@@ -36,10 +36,11 @@ for b in range(nb):
     nan_eq = bool(np.array_equal(np.isnan(hm), np.isnan(rf)))
     peak = max(float(np.nanmax(np.abs(rf))), 1e-6)
     dev = float(np.nanmax(np.abs(hm - rf))) / peak if nan_eq else float("nan")
+    n_diff = int((hm[np.isfinite(rf)] != rf[np.isfinite(rf)]).sum()) if nan_eq else -1
     rel_eq = bool(np.array_equal(out["output_reliable"][b].cpu().numpy().astype(bool), o["output_reliable_crop"]))
     s = out["scalars"][b].cpu().numpy()
     arg_eq = int(s[4]) == int(o["argmax_depth_index"])
     ok = nan_eq and rel_eq and arg_eq and dev <= 1e-4 and int(out["status"][b]) == 0
     strict += ok
-    print(f"frame {start + b} {'ok ' if ok else 'BAD'} nan_equal {nan_eq} reliable_equal {rel_eq} argmax_equal {arg_eq} map {dev:.2e} ({time.time() - t0:.0f} s oracle)", flush=True)
+    print(f"frame {start + b} {'ok ' if ok else 'BAD'} nan_equal {nan_eq} reliable_equal {rel_eq} argmax_equal {arg_eq} map {dev:.2e} of peak {peak:.4f} mm, {n_diff} differing px ({time.time() - t0:.0f} s oracle)", flush=True)
 print(f"strict {strict} / {nb}")
