@@ -43,7 +43,12 @@ extern "C" {
 #define VISTAF_FRAME_OK 0
 #define VISTAF_FRAME_EMPTY_RELIABLE 1   /* upstream: main() logs and returns None (shape_ftp.py:1677-1679) */
 #define VISTAF_FRAME_QUEUE_OVERFLOW 2   /* internal work queue exhausted (never for valid sizes) */
-#define VISTAF_FRAME_NO_CARRIER 3       /* pair mode: no usable carrier peak in this sample's reference frame */
+#define VISTAF_FRAME_NO_CARRIER 3       /* pair mode: no usable carrier peak in this sample's reference frame.  DELIBERATE RESTRICTION: a
+                                         * carrier whose (2*patch_half_width_bins+1)^2 patch is clipped by the spectrum border (carrier
+                                         * within 10 bins of Nyquist, i.e. a fringe period of ~2 px) is refused in pair mode, whereas
+                                         * upstream clips the patch and goes on (shape_ftp.py:930-948); session mode (set_reference)
+                                         * accepts clipped patches as upstream does.  Parity for that edge is unpinned (no stored
+                                         * output of the reference covers it). */
 
 /* input frame formats */
 #define VISTAF_FMT_GRAY_U8 0    /* [B,h,w] uint8 (cv2.cvtColor(...,BGR2GRAY) already applied) */
@@ -168,7 +173,8 @@ int vistaf_ftp_predict_batch(vistaf_ftp_handle *hd, const void *d_frames, int fo
 /* Uncached pairs: sample b = (d_refs[b], d_defs[b]), both in `format`; every sample's reference frame is demodulated with its own
  * carrier search and its deformed frame locked to that carrier -- what Code/height_to_force.py:384 does when it calls shape_ftp.main once
  * per image (shape_ftp.py:1632-1653).  Needs no vistaf_ftp_set_reference.  Outputs as vistaf_ftp_predict_batch; d_status[b] =
- * VISTAF_FRAME_NO_CARRIER when sample b's reference spectrum has no usable carrier peak.  Asynchronous on `stream`. */
+ * VISTAF_FRAME_NO_CARRIER when sample b's reference spectrum has no usable carrier peak.  Asynchronous on `stream`, except that the
+ * first call and every call with a larger batch than any before allocate (and release) the carrier-search buffers, which synchronises. */
 int vistaf_ftp_predict_pairs(vistaf_ftp_handle *hd, const void *d_refs, const void *d_defs, int format, int batch,
                              float *d_height_mm, uint8_t *d_reliable, double *d_scalars, int32_t *d_status, void *stream);
 

@@ -59,6 +59,9 @@ void vistaf_tempseg_destroy(vistaf_tempseg_handle *h);
 /* d_bgr [H,W,3] uint8 (cv2.imread order), d_roi [H,W] uint8 0/1 (roi_full).  Outputs [H,W] uint8 0/1, any may be NULL:
  * d_dark / d_light (dark_final, light_final), d_roi_eff, d_sat; info_host[VISTAF_TEMPSEG_NINFO] on the HOST.
  * Errors as upstream: VISTAF_E_STATE when the ROI is empty after the saturation exclusion (:445-446).  Synchronises `stream`. */
+/* DELIBERATE RESTRICTION: returns VISTAF_E_NOCARRIER ("carrier band leaves the spectrum") when the band-pass disc of radius
+ * bandpass_radius_bins around the carrier peak is clipped by the spectrum border; upstream multiplies by the clipped disc and goes on
+ * (temperature_sensor.py:463-468).  Such a carrier is within 22 bins of Nyquist (stripe period ~2 px); parity for that edge is unpinned. */
 int vistaf_tempseg_segment(vistaf_tempseg_handle *h, const uint8_t *d_bgr, const uint8_t *d_roi, uint8_t *d_dark, uint8_t *d_light,
                            uint8_t *d_roi_eff, uint8_t *d_sat, double *info_host, void *stream);
 

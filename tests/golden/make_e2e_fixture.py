@@ -28,20 +28,23 @@ from oracle import ftp_oracle as O            # noqa: E402
 
 REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
 NAMES = ["FINAL_E_deformed", "FINAL_F_deformed", "FINAL_P_deformed", "FINAL_ROUND_METAL", "FINAL_TEMP_DEMO"]
-FIXTURES = ["FINAL_E_deformed"]
+FIXTURES = list(NAMES)          # round 3: every stored bundle goes through the HIP path (the reference crop is stored once, in the FINAL_E file)
 CIRCLE_PTS = ((1873, 1703), (1599, 707), (2575, 950))      # shape_ftp.py:41-43
 
 
 def main():
     cfg = O.OracleConfig()
     cal, neg = O.load_calibration(os.path.join(ROOT, "tests", "golden", "calibration_phase_to_height.json"))
+    fm = json.load(open(os.path.join(ROOT, "tests", "golden", "calibration_height_to_force.json")))["best_model"]
+    stored_tails = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_tail_demos.json")))["demos"]     # the reference's five result.json
     rows = []
+    ref_crop = None
     for name in NAMES:
         bun = np.load(f"{REF}/Multimodal_Sensor/Demos_report/{name}/force_sensing/ftp_run/height_map_bundle.npz")
         t0 = time.time()
         rg, dg, (cx, cy, r), info = A.aligned_crops(f"{REF}/Final_demos_images/FINAL_reference.jpg", f"{REF}/Final_demos_images/{name}.jpg", CIRCLE_PTS)
         rs = O.make_reference_state(rg, cx, cy, r, cfg)
-        out = O.process_frame(dg, rs, cfg, cal, neg, None)
+        out = O.process_frame(dg, rs, cfg, cal, neg, fm)
         hm, g = out["height_map_mm_crop"], bun["height_crop"]
         both = np.isfinite(hm) & np.isfinite(g)
         d = np.abs(hm[both] - g[both])
@@ -56,12 +59,20 @@ def main():
             "iou_contact_kept": iou(out["contact_kept_by_depth"].astype(bool), bun["crop_contact_kept_by_depth"]),
             "seconds": round(time.time() - t0, 1),
         }
+        # the force tail of the oracle chain beside the reference's stored result.json (relative deviations)
+        st = stored_tails[name]["stored"]
+        row["tail"] = {k: float(out[k]) for k in ("estimated_grating_period_px", "mm_per_px", "volume_cm3", "contact_area_mm2", "max_depth_mm", "force_N")}
+        row["tail_rel_dev"] = {k: abs(row["tail"][k] - st[k]) / abs(st[k]) for k in row["tail"]}
         rows.append(row)
         print(json.dumps(row), flush=True)
+        if ref_crop is None:
+            ref_crop = rg
+        assert np.array_equal(rg, ref_crop)          # the reference crop does not depend on the deformed photograph
         if name in FIXTURES:
+            extra = {"ref_gray": rg} if name == NAMES[0] else {}
             np.savez_compressed(
                 os.path.join(ROOT, "tests", "golden", f"e2e_{name}.npz"),
-                ref_gray=rg, def_gray_aligned=dg, circle=np.array([cx, cy, r], np.int32),
+                def_gray_aligned=dg, ecc_failed=np.array(info["ecc_iters"] == 0), **extra, circle=np.array([cx, cy, r], np.int32),
                 height_crop_reference=g.astype(np.float32),
                 reliable_bits=np.packbits(bun["crop_reliable"]), contact_dilated_bits=np.packbits(bun["crop_contact_dilated"]),
                 contact_kept_bits=np.packbits(bun["crop_contact_kept_by_depth"]), output_reliable_bits=np.packbits(bun["crop_output_reliable"]),

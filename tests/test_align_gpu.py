@@ -140,3 +140,46 @@ def test_phase_to_height_batch_job_driver(pkg, photos):
     assert r["file"] == stored["file"] and r["depth_mm"] == float(stored["depth_mm"]) and r["heightmap_figure"] == stored["heightmap_figure"]
     assert abs(r["min_height_unitless"] - float(stored["min_height_unitless"])) <= 5e-4, r
     assert (r["min_x"], r["min_y"]) == (int(stored["min_x"]), int(stored["min_y"])), r
+
+
+def test_all_four_stored_arg_min_locations_through_the_hip_path(pkg, photos):
+    """the reference's ONLY stored contact-location goldens -- the four rows of
+    `Force/Phase_to_height/calibration_out/calibration_results.csv` (tests/golden/ref_phase_to_height_results.csv: (703,514), (607,524),
+    (729,537), (722,588)) -- through `calibrate.phase_to_height_rows` on the reference's own four calibration photographs
+    (tests/golden/Height_*mm_deformed.jpg, data files): photograph -> GPU alignment (OpenCV 3.x BGR2GRAY, the generation that
+    reproduces this data set) -> HIP path with Code/phase_to_height.py's constants -> (min, x, y).
+
+    Two bars: (a) the HIP path on the ORACLE-aligned crop of each photograph (alignment restatement on the CPU, so that only the path
+    differs): the stored pixel EXACTLY and the oracle's minimum to 1e-4; (b) the full GPU chain (GPU alignment + HIP path, one batch of four):
+    the stored pixel exactly, the stored minimum within 5e-3 relative (restated alignment; the oracle chain measures 3.4e-3,
+    tests/golden/e2e_phase_to_height_report.json)."""
+    import csv
+    import json
+    from oracle import align_oracle as A
+    cal, neg = pkg.load_calibration(os.path.join(G, "calibration_phase_to_height.json"))
+    fm = pkg.load_force_calibration(os.path.join(G, "calibration_height_to_force.json"))["best_model"]
+    stored = list(csv.DictReader(open(os.path.join(G, "ref_phase_to_height_results.csv"))))
+    report = {r["file"]: r for r in json.load(open(os.path.join(G, "e2e_phase_to_height_report.json")))}
+    assert [r["file"] for r in stored] == ["Height_0.5mm_deformed.jpg", "Height_1mm_deformed.jpg", "Height_1.5mm_deformed.jpg", "Height_2mm_deformed.jpg"]
+    al = pkg.FtpAligner(photos[0], max_batch=4, gray_coeffs=1)
+    sensor = pkg.FtpSensor(al.reference_gray_crop, al.circle_crop, pkg.FtpConfig.phase_to_height(), cal, neg, fm, max_batch=4)
+    items = [(r["file"], _imread_bgr(os.path.join(G, r["file"]))) for r in stored]
+    # (b) the whole chain on the GPU, the four photographs as one batch
+    rows = pkg.calibrate.phase_to_height_rows(al, sensor, items, [float(r["depth_mm"]) for r in stored], batch=4)
+    for r, s in zip(rows, stored):
+        assert (r["min_x"], r["min_y"]) == (int(s["min_x"]), int(s["min_y"])), (r, s)
+        assert abs(r["min_height_unitless"] - float(s["min_height_unitless"])) <= 5e-3 * abs(float(s["min_height_unitless"])), (r, s)
+        assert r["file"] == s["file"] and r["depth_mm"] == float(s["depth_mm"]) and r["heightmap_figure"] == s["heightmap_figure"]
+    # (a) oracle-aligned crops -> HIP path: the path alone
+    pts = ((1873, 1703), (1599, 707), (2575, 950))
+    i_min, i_arg = pkg.SCALAR_NAMES.index("min_height_unitless"), pkg.SCALAR_NAMES.index("argmin_unitless_index")
+    crops = []
+    for s in stored:
+        rg, dg, circle, _info = A.aligned_crops(os.path.join(G, "FINAL_reference.jpg"), os.path.join(G, s["file"]), pts, gray_generation=3)
+        assert circle == al.circle_crop and np.array_equal(rg, al.reference_gray_crop.cpu().numpy())
+        crops.append(dg)
+    sc = sensor.predict_batch(np.stack(crops))["scalars"].cpu().numpy()
+    for j, s in enumerate(stored):
+        flat = int(sc[j, i_arg])
+        assert (flat % 1182, flat // 1182) == (int(s["min_x"]), int(s["min_y"])), (s["file"], flat % 1182, flat // 1182)
+        assert abs(float(sc[j, i_min]) - report[s["file"]]["min"]) <= 1e-4 * abs(report[s["file"]]["min"]), s["file"]

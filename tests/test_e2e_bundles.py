@@ -8,8 +8,13 @@ ITSELF stored for that pair (`Multimodal_Sensor/Demos_report/FINAL_E_deformed/fo
 This is the test that pins the cv2-dependent stages of the oracle (blur, Sobel, morphology, connected components,
 distance transform, Telea inpaint): none of the reference's own files pins them stage by stage, but its stored output
 does end to end.  Tolerances are those of a restated alignment (JPEG decoder and float reductions differ from OpenCV's):
-measured 6.1e-5 mm mean / 2.7e-3 mm max against a 1.12 mm peak, masks equal to 1.5e-5 of the pixels; the table for all
-five stored pairs is tests/golden/e2e_bundles_report.json (mean 6e-5 .. 2.7e-4 mm, reliable-mask IoU >= 0.9999).
+measured on FINAL_E 2.9e-5 mm mean / 2.4e-3 mm max against a 1.12 mm peak, masks equal to 1e-5 of the pixels; the table for all
+five stored pairs is tests/golden/e2e_bundles_report.json (mean 2.9e-5 .. 3.1e-4 mm, max 2.4e-3 .. 6.9e-3 mm, reliable-mask
+IoU >= 0.99996).  tests/golden/e2e_residual_isolation.json shows that this residual is the size of ONE quantisation step of the
+pre-path (a 1/32-px step of warpAffine's shift, +-1 grey level of decoder noise), i.e. alignment / decode noise, not the path.
+
+Round 3: ALL FIVE stored bundles are committed fixtures (e2e_<name>.npz; the reference crop is stored once, in the FINAL_E file) and go
+through the HIP path at native 1182 x 1182 with as-shipped constants, together with the five stored result.json tails.
 """
 import json
 import os
@@ -23,11 +28,19 @@ G = os.path.join(os.path.dirname(__file__), "golden")
 N = 1182
 
 
-def _fixture():
-    z = np.load(os.path.join(G, "e2e_FINAL_E_deformed.npz"))
+NAMES = ["FINAL_E_deformed", "FINAL_F_deformed", "FINAL_P_deformed", "FINAL_ROUND_METAL", "FINAL_TEMP_DEMO"]
+
+
+def _report_row(name):
+    return [r for r in json.load(open(os.path.join(G, "e2e_bundles_report.json"))) if r["name"] == name][0]
+
+
+def _fixture(name="FINAL_E_deformed"):
+    z = np.load(os.path.join(G, f"e2e_{name}.npz"))
     unpack = lambda k: np.unpackbits(z[k])[: N * N].reshape(N, N).astype(bool)
     return {
-        "ref": z["ref_gray"], "def": z["def_gray_aligned"], "circle": tuple(int(v) for v in z["circle"]),
+        "ref": np.load(os.path.join(G, "e2e_FINAL_E_deformed.npz"))["ref_gray"], "def": z["def_gray_aligned"], "circle": tuple(int(v) for v in z["circle"]),
+        "ecc_failed": bool(z["ecc_failed"]),
         "height": z["height_crop_reference"], "reliable": unpack("reliable_bits"), "contact_dilated": unpack("contact_dilated_bits"),
         "contact_kept": unpack("contact_kept_bits"), "output_reliable": unpack("output_reliable_bits"),
     }
@@ -43,9 +56,9 @@ def _check_against_reference(height, output_reliable, fx):
     m = np.isfinite(g)
     d = np.abs(height[m] - g[m])
     peak = float(np.nanmax(g))
-    assert abs(float(np.nanmax(height)) - peak) <= 5e-4 * peak                 # measured 2.0e-4 (2.3e-5 before the blur took cv's fused form: alignment noise)
-    assert float(d.mean()) <= 2e-4 and float(d.max()) <= 6e-3                  # mm; measured 6.1e-5 / 2.7e-3
-    assert float(np.percentile(d, 99)) <= 2e-3                                 # measured 8.5e-4
+    assert abs(float(np.nanmax(height)) - peak) <= 5e-4 * peak                 # measured 9.3e-5 (e2e_bundles_report.json)
+    assert float(d.mean()) <= 2e-4 and float(d.max()) <= 6e-3                  # mm; measured 2.9e-5 / 2.4e-3
+    assert float(np.percentile(d, 99)) <= 2e-3                                 # measured 3.2e-4
     assert _iou(output_reliable.astype(bool), fx["output_reliable"]) >= 0.9999
 
 
@@ -81,33 +94,6 @@ def test_alignment_restatement_regenerates_fixture():
     assert np.array_equal(rg, fx["ref"])
     assert np.array_equal(dg, fx["def"])
     assert 10 <= info["ecc_iters"] < 300 and info["rho"] > 0.8
-
-
-@pytest.mark.gpu
-def test_hip_path_reproduces_reference_bundle_on_real_photo(pkg):
-    """The product path at the reference's native size and as-shipped constants, on the real photograph pair, against
-    the height map the reference stored -- and against the oracle at the usual 1e-4 float32 tolerance."""
-    import torch
-    fx = _fixture()
-    cal, neg = pkg.load_calibration(os.path.join(G, "calibration_phase_to_height.json"))
-    fm = pkg.load_force_calibration(os.path.join(G, "calibration_height_to_force.json"))["best_model"]
-    cfg = pkg.FtpConfig.as_shipped()
-    sensor = pkg.FtpSensor(fx["ref"], fx["circle"], cfg, cal, neg, fm, max_batch=1)
-    out = sensor.predict_batch(fx["def"][None])
-    torch.cuda.synchronize()
-    assert int(out["status"][0]) == 0
-    hm = out["height_map_mm"][0].cpu().numpy()
-    rel = out["output_reliable"][0].cpu().numpy().astype(bool)
-    _check_against_reference(hm, rel, fx)
-    ocfg = O.OracleConfig()
-    rs = O.make_reference_state(fx["ref"], *fx["circle"], ocfg)
-    o = O.process_frame(fx["def"], rs, ocfg, cal, neg, fm)
-    ref = o["height_map_mm_crop"]
-    peak = float(np.nanmax(np.abs(ref)))
-    diff = np.nan_to_num(np.abs(hm - ref))
-    assert float(diff.max()) <= 1e-4 * peak                                     # the strict bar of tests/test_gpu_parity.py, every pixel
-    assert np.array_equal(rel, o["output_reliable_crop"])
-    assert int(out["scalars"][0, 4]) == o["argmax_depth_index"]
 
 
 @pytest.mark.gpu
@@ -175,3 +161,86 @@ def test_arg_extremum_locations_under_phase_to_height_constants():
         assert r["xy"] == r["stored_xy"]
         assert abs(r["min"] - r["stored_min"]) <= 5e-3 * abs(r["stored_min"])
     assert abs(rows[3]["min"] - rows[3]["stored_min"]) <= 1e-4 * abs(rows[3]["stored_min"])
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# Round 3: every reference-held golden of the path through the HIP kernels
+# ------------------------------------------------------------------------------------------------------------------------------------
+def _check_pair_against_stored(height, output_reliable, fx, row):
+    """`row`: the oracle-vs-stored line of e2e_bundles_report.json for this pair.  The HIP map equals the oracle's to 1e-4 of the peak per
+    pixel (asserted separately), so against the reference's STORED map it may deviate by what the oracle chain deviates (restated
+    decode + alignment, see e2e_residual_isolation.json) plus that bar -- and by no more than the caps of the five-pair table."""
+    g = fx["height"]
+    assert np.array_equal(np.isfinite(height), np.isfinite(g))                 # NaN layout (ROI) identical to the stored bundle
+    m = np.isfinite(g)
+    d = np.abs(height[m] - g[m])
+    peak = float(np.nanmax(g))
+    bar = 1e-4 * peak
+    assert float(d.max()) <= row["abs_diff_max_mm"] + bar and float(d.max()) <= 8e-3
+    assert float(d.mean()) <= row["abs_diff_mean_mm"] + bar and float(d.mean()) <= 4e-4
+    assert float(np.percentile(d, 99)) <= row["abs_diff_p99_mm"] + bar
+    assert abs(float(np.nanmax(height)) - peak) <= abs(row["peak_mm_oracle"] - row["peak_mm_reference"]) + bar
+    assert _iou(output_reliable.astype(bool), fx["output_reliable"]) >= 0.9999
+
+
+@pytest.mark.parametrize("name", NAMES[1:])
+def test_fixture_of_every_stored_bundle_is_consistent(name):
+    """data check on CPU (the oracle run itself is recorded in e2e_bundles_report.json; FINAL_E runs it live above)"""
+    fx = _fixture(name)
+    row = _report_row(name)
+    assert fx["def"].shape == (N, N) and fx["def"].dtype == np.uint8 and fx["circle"] == (591, 591, 590)
+    assert fx["ecc_failed"] == (row["ecc_iters"] == 0) == (name in ("FINAL_ROUND_METAL", "FINAL_TEMP_DEMO"))
+    assert abs(float(np.nanmax(fx["height"])) - row["peak_mm_reference"]) < 1e-9
+    assert np.array_equal(np.isfinite(fx["height"]), fx["output_reliable"] | np.isfinite(fx["height"]))
+    for k in ("volume_cm3", "contact_area_mm2", "max_depth_mm", "force_N"):
+        assert row["tail_rel_dev"][k] <= 2e-2, (name, k)                         # the oracle chain vs the reference's result.json
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_hip_path_reproduces_every_stored_bundle_and_result_json(pkg, name):
+    """All five stored `height_map_bundle.npz` + `result.json` of the reference (Multimodal_Sensor/Demos_report/<name>/force_sensing/),
+    HIP path at native size with as-shipped constants, incl. the two pairs whose ECC update fails upstream (unaligned crop used,
+    shape_ftp.py:576-578).  Three bars per pair:
+      (1) against the oracle on the same aligned crops: 1e-4 of the map's peak on EVERY pixel, output_reliable equal, arg-max index exact;
+      (2) against the reference's stored map and masks: the oracle chain's own recorded deviation + (1)  (see _check_pair_against_stored);
+      (3) the five stored forces / volumes / areas / max depths: what the oracle chain's tail deviates (e2e_bundles_report.json `tail_rel_dev`:
+          restated alignment) + 1e-4 relative (force: times the curve's condition number, capped at 4)."""
+    import torch
+    fx = _fixture(name)
+    row = _report_row(name)
+    cal, neg = pkg.load_calibration(os.path.join(G, "calibration_phase_to_height.json"))
+    fcal = pkg.load_force_calibration(os.path.join(G, "calibration_height_to_force.json"))
+    fm = fcal["best_model"]
+    sensor = pkg.FtpSensor(fx["ref"], fx["circle"], pkg.FtpConfig.as_shipped(), cal, neg, fm, max_batch=1)
+    res = sensor.predict(fx["def"])
+    torch.cuda.synchronize()
+    assert res is not None
+    hm, rel = res["height_map_mm_crop"], res["output_reliable_crop"].astype(bool)
+    # (1) oracle, same inputs
+    ocfg = O.OracleConfig()
+    rs = O.make_reference_state(fx["ref"], *fx["circle"], ocfg)
+    o = O.process_frame(fx["def"], rs, ocfg, cal, neg, fm)
+    ref = o["height_map_mm_crop"]
+    peak = float(np.nanmax(np.abs(ref)))
+    assert np.array_equal(np.isnan(hm), np.isnan(ref))
+    assert float(np.nan_to_num(np.abs(hm - ref)).max()) <= 1e-4 * peak
+    assert np.array_equal(rel, o["output_reliable_crop"])
+    assert int(res["argmax_depth_index"]) == o["argmax_depth_index"]
+    # (2) the reference's stored bundle
+    _check_pair_against_stored(hm, rel, fx, row)
+    masks = sensor.masks(0)
+    for key, ref_mask, rk in (("reliable", fx["reliable"], "iou_reliable"), ("contact_dilated", fx["contact_dilated"], "iou_contact_dilated"),
+                              ("contact_kept_by_depth", fx["contact_kept"], "iou_contact_kept")):
+        assert _iou(np.asarray(masks[key]).astype(bool), ref_mask) >= row[rk] - 1e-4, key
+    # (3) the reference's stored result.json
+    stored = json.load(open(os.path.join(G, "ref_tail_demos.json")))["demos"][name]["stored"]
+    rec = pkg.result_record(res, fm, "./Force/FINAL_reference.jpg", f"./Final_demos_images/{name}.jpg", "o", "o/ftp_run")
+    a, b = fm["params"]["a"], fm["params"]["b"]
+    v = stored["volume_cm3"]
+    kappa = min(4.0, max(1.0, b * v * np.exp(b * v) / (np.exp(b * v) - 1.0)))             # growth curve a (e^{bV} - 1): |V f'(V) / f(V)|
+    for k, extra in (("estimated_grating_period_px", 1.0), ("mm_per_px", 1.0), ("max_depth_mm", 1.0), ("contact_area_mm2", 1.0), ("volume_cm3", 1.0), ("force_N", kappa)):
+        dev = abs(rec[k] - stored[k]) / abs(stored[k])
+        assert dev <= row["tail_rel_dev"][k] + 1e-4 * extra, (name, k, dev, row["tail_rel_dev"][k])
+    # the curve evaluation itself is checked tightly on the GPU's own volume (ADVICE r2: only the volume carries the 1e-4 bar)
+    assert abs(rec["force_N"] - a * (np.exp(b * rec["volume_cm3"]) - 1.0)) <= 1e-12 * max(1.0, abs(rec["force_N"]))

@@ -34,7 +34,8 @@ def _sensor(pkg, cal, n, cfg, max_batch, ref=None, **kw):
 
 
 def _check_frame(out, b, o, n, check_argmin=True):
-    """compare GPU outputs of frame b against oracle result dict o"""
+    """compare GPU outputs of frame b against oracle result dict o.  RTOL (1e-4) is relative to the map's PEAK (a depth map is zero over
+    most of the ROI, a per-pixel relative bar is meaningless there): every pixel within 1e-4 * max|map|; scalars within 1e-4 relative."""
     hm = out["height_map_mm"][b].cpu().numpy()
     ref = o["height_map_mm_crop"]
     assert int(out["status"][b]) == 0
@@ -61,7 +62,11 @@ def _check_frame(out, b, o, n, check_argmin=True):
         kappa = abs((O.predict_force_from_volume(_FORCE_MODEL[0], V + dV) - O.predict_force_from_volume(_FORCE_MODEL[0], V - dV)) / (2 * dV) * V / F)
     else:
         kappa = 1.0
-    assert abs(s[3] - F) <= RTOL * max(1.0, kappa) * max(abs(F), 1e-9), "force_N"
+    # the widening is capped (a genuine force-tail error must not hide behind a large condition number), and the curve
+    # evaluation itself is checked tightly on the GPU's OWN volume, so that only the volume carries the 1e-4 bar.
+    assert abs(s[3] - F) <= RTOL * min(4.0, max(1.0, kappa)) * max(abs(F), 1e-9), "force_N"
+    if _FORCE_MODEL[0] is not None:
+        assert abs(s[3] - O.predict_force_from_volume(_FORCE_MODEL[0], float(s[0]))) <= 1e-12 * max(1.0, abs(s[3])), "force curve on the GPU's own volume"
     # the carrier peak is refined in float32 from spectrum magnitudes: equal to ~1 ulp of the peak position
     assert abs(s[5] - o["estimated_grating_period_px"]) <= 1e-5 * s[5] and abs(s[6] - o["mm_per_px"]) <= 1e-5 * s[6]
     assert int(s[9]) == int(o["reliable"].sum())

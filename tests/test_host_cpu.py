@@ -171,6 +171,73 @@ def test_two_rank_all_gather_gloo(pkg):
     assert res == [(0, True), (1, True)]
 
 
+def _ragged_worker(rank, world, port, pkg_name, q):
+    """shard_range(2050, r, 8) gives shards of 257 and 256 frames: the same raggedness with two ranks is total = 515 -> 258 + 257."""
+    import importlib
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    par = importlib.import_module(pkg_name + ".parallel")
+    sizes8 = [b - a for a, b in (par.shard_range(2050, r, 8) for r in range(8))]
+    ok = sizes8 == [257, 257, 256, 256, 256, 256, 256, 256]
+    total, h = 515, 6
+    a, b = par.shard_range(total, rank, world)
+    ok = ok and (b - a) == (258 if rank == 0 else 257)
+    full_h = torch.arange(total * h * h, dtype=torch.float32).reshape(total, h, h) + 1.0
+    full_s = torch.arange(total * 16, dtype=torch.float64).reshape(total, 16) + 1.0
+    full_st = torch.arange(total, dtype=torch.int32) + 1
+    local = {"height_map_mm": full_h[a:b].clone(), "scalars": full_s[a:b].clone(), "status": full_st[a:b].clone()}
+    # (1) unequal shards without `total`: refused on EVERY rank at construction, before any data-path collective
+    try:
+        par.PackedGather(local, keys=("height_map_mm", "scalars", "status"))
+        raised = False
+    except ValueError as e:
+        raised = "shards differ" in str(e)
+    ok = ok and raised
+    # (2) with `total`: the short shard is padded, still ONE collective per step, compact() restores the global order
+    calls = {"n": 0}
+    orig = dist.all_gather_into_tensor
+
+    def counting(*args, **kw):
+        calls["n"] += 1
+        return orig(*args, **kw)
+    dist.all_gather_into_tensor = counting
+    pg = par.PackedGather(local, keys=("height_map_mm", "scalars", "status"), total=total)
+    for _ in range(2):
+        pg.gather(local)
+    dist.all_gather_into_tensor = orig
+    c = pg.compact()
+    ok = ok and calls["n"] == 2 and pg.padded and pg.b == 258 and pg.sizes == [258, 257]
+    ok = ok and torch.equal(c["height_map_mm"], full_h) and torch.equal(c["scalars"], full_s) and torch.equal(c["status"], full_st)
+    v = pg.views()
+    ok = ok and v["status"].shape[0] == 2 * 258 and int(v["status"][2 * 258 - 1]) == 0          # the padding row of the short shard stays zero
+    # (3) a rank that holds the wrong number of frames for `total` is refused
+    try:
+        par.PackedGather({k: t[:-1] for k, t in local.items()}, keys=("height_map_mm",), total=total)
+        ok = False
+    except ValueError:
+        pass
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_short_last_shard_is_padded_or_refused_gloo(pkg):
+    """PackedGather used to assume equal shards silently."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_ragged_worker, args=(r, 2, port, pkg.__name__, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
+
+
 def _bench_flow_worker(rank, world, port, q):
     """bench.py's own step / timing control flow (Stepper, timed_steps, PackedGather with GATHER_KEYS) on CPU tensors of the REAL output
     shapes and dtypes of a 256-frame shard, gloo instead of RCCL; every collective is counted."""

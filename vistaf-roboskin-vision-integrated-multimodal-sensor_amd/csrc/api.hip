@@ -2,6 +2,7 @@
 // every image operation runs in a HIP kernel of this library; the host builds constant tables
 // (Gaussian taps, Hann window, DFT twiddles, ROI / apodisation planes) in double precision.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -444,11 +445,22 @@ static int reference_search(vistaf_ftp_handle *hd, int nb, CarrierGeom *geom_dev
             if ((rc = dalloc(hd, &hd->Exf, (size_t)w * (Wf / 2 + 1))) || (rc = dalloc(hd, &hd->Eyf, (size_t)Hf * h))) return rc;
             launch_build_full_tables(hd->Exf, hd->Eyf, h, w, pad, Hf, Wf, st);
         }
-        // (a smaller earlier set stays owned by the handle until destroy; this only grows when pair mode follows session mode)
-        if ((rc = dalloc(hd, &hd->search_tmp, (size_t)nb * h * (Wf / 2 + 1) + 64)) || (rc = dalloc(hd, &hd->search_mag, (size_t)nb * Hf * Wf)) ||
-            (rc = dalloc(hd, &hd->search_peaks, (size_t)nb * 192)))
+        // The search buffers grow geometrically (at least doubling, at most max_batch frames) and the previous set is RELEASED here, not
+        // kept until destroy: a caller whose pair batches grow (1, 2, ..., max_batch) holds one set of <= max_batch frames at any time
+        // instead of piling up O(max_batch^2) frames of Hf x Wf doubles.  (The first pair-mode call and every growth allocate, i.e. synchronise.)
+        const int cap = std::min(std::max(nb, 2 * hd->search_cap), std::max(nb, hd->maxB));
+        if (hd->search_cap > 0) {
+            HIPCHK(hipStreamSynchronize(st));          // earlier searches on this stream may still read the old set
+            for (void *q : {(void *)hd->search_tmp, (void *)hd->search_mag, (void *)hd->search_peaks}) {
+                auto it = std::find(hd->allocs.begin(), hd->allocs.end(), q);
+                if (it != hd->allocs.end()) { hipFree(q); hd->allocs.erase(it); }
+            }
+            hd->search_tmp = nullptr; hd->search_mag = nullptr; hd->search_peaks = nullptr; hd->search_cap = 0;
+        }
+        if ((rc = dalloc(hd, &hd->search_tmp, (size_t)cap * h * (Wf / 2 + 1) + 64)) || (rc = dalloc(hd, &hd->search_mag, (size_t)cap * Hf * Wf)) ||
+            (rc = dalloc(hd, &hd->search_peaks, (size_t)cap * 192)))
             return rc;
-        hd->search_cap = nb;
+        hd->search_cap = cap;
     }
     const int npk = std::min(std::max(1, c.n_fft_peaks), 64);
     launch_dft_full_mag(hd->iw, hd->mu, hd->Exf, hd->Eyf, hd->search_tmp, hd->search_mag, nb, h, w, Hf, Wf, st);
