@@ -422,6 +422,10 @@ static void calc_fmm(uint8_t *f, float *t, pq_t *q, int er, int ec, int negate)
             if (f[p] == F_CHANGE) { f[p] = F_KNOWN; t[p] = -t[p]; }
 }
 
+/* optional log of the march's fill sequence (diagnostics and the test of the GPU's ordering pass): fill number per pixel, -1 = not filled */
+static int32_t *g_fill_index = NULL;
+static int32_t g_fill_count = 0;
+
 void cvl_inpaint_telea_f32(const float *src, const uint8_t *inpaint_mask, float *dst, int h, int w, double radius)
 {
     int range = cv_round(radius);
@@ -547,10 +551,21 @@ void cvl_inpaint_telea_f32(const float *src, const uint8_t *inpaint_mask, float 
 #undef TT
 #undef OO
             f[(size_t)i * ec + j] = F_BAND;
+            if (g_fill_index) g_fill_index[(size_t)(i - 1) * w + (j - 1)] = g_fill_count++;
             pq_push(&heap, i, j, dist);
         }
     }
     free(heap.e); free(outq.e); free(t); free(mask); free(band); free(out);
+}
+
+/* the same call, also reporting the order in which the march filled the hole pixels (0, 1, 2, ...; -1 elsewhere); returns the count */
+int cvl_inpaint_telea_f32_order(const float *src, const uint8_t *inpaint_mask, float *dst, int32_t *fill_index, int h, int w, double radius)
+{
+    for (size_t p = 0; p < (size_t)h * w; p++) fill_index[p] = -1;
+    g_fill_index = fill_index; g_fill_count = 0;
+    cvl_inpaint_telea_f32(src, inpaint_mask, dst, h, w, radius);
+    g_fill_index = NULL;
+    return g_fill_count;
 }
 
 /* ------------------------------------------------------------------------------------------- */

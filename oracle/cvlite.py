@@ -156,6 +156,19 @@ def inpaint_telea(src, mask, radius: float) -> np.ndarray:
     return dst
 
 
+def inpaint_telea_order(src, mask, radius: float):
+    """inpaint_telea plus the march's fill sequence: (dst, fill_index int32 [h, w], -1 where nothing was filled)."""
+    src = _f32(src)
+    m = _u8(mask)
+    dst = np.empty_like(src)
+    order = np.empty(src.shape, np.int32)
+    h, w = src.shape
+    f = lib().cvl_inpaint_telea_f32_order
+    f.restype = ctypes.c_int
+    f(_p(src), _p(m), _p(dst), _p(order), ctypes.c_int(h), ctypes.c_int(w), ctypes.c_double(radius))
+    return dst, order
+
+
 def unwrap_quality_guided(wrapped, mask, quality, want_tree: bool = False):
     """shape_ftp.unwrap_quality_guided (shape_ftp.py:1043-1080), exact heap order."""
     wrapped = _f32(wrapped)

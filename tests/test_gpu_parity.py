@@ -465,7 +465,14 @@ def test_inpaint_window_tier_against_sequential_tier_and_oracle_on_many_frames(p
         o = O.process_frame(frames[b], rs, cfg, *cal, keep_intermediates=True)
         di = o["inter"]["demod"]["inter"]
         assert np.array_equal(bad0[b] != 0, di["bad"])
-        assert float(np.abs(img0[b] - di["img_inpainted"]).max()) <= 1e-5 * 255
+        assert np.array_equal(img0[b], di["img_inpainted"]), b             # the window tiers sum in OpenCV's order: same bits
+    # the 16-wave first tier (ordering pass + dataflow fills, k_inpaint_mw.hip) against the single-wave window march: same bits on every frame
+    sensor._test_set("inpaint_tier", 2)
+    sensor._test_set("telea_mw", 0)
+    sensor.predict_batch(frames)
+    torch.cuda.synchronize()
+    img2 = sensor.intermediate("img", nb).cpu().numpy().reshape(nb, n, n)
+    assert np.array_equal(img0, img2)
 
 
 def test_march_lds_tiers_retry_and_whole_frame_fallback(pkg, cal):
@@ -504,6 +511,12 @@ def test_march_lds_tiers_retry_and_whole_frame_fallback(pkg, cal):
     sensor.predict_batch(frames)
     torch.cuda.synchronize()
     assert np.array_equal(sensor.intermediate("img", 3).cpu().numpy().reshape(3, n, n), img_a)
+    for two_tier in (1, 0):                      # and without the 16-wave first tier (frame 0 then marches on the single-wave tiers)
+        sensor._test_set("telea_mw", 0)
+        sensor._test_set("telea_two_tier", two_tier)
+        sensor.predict_batch(frames)
+        torch.cuda.synchronize()
+        assert np.array_equal(sensor.intermediate("img", 3).cpu().numpy().reshape(3, n, n), img_a)
 
 
 def test_sixty_four_more_frames_against_oracle(pkg, cal):

@@ -17,7 +17,7 @@
 using namespace vf;
 #include "test_hooks.h"
 #ifdef VISTAF_DEBUG
-namespace vf { void telea_debug_dump(); void telea_window_debug_dump(int B); void unwrap_big_debug_dump(); void unwrap_batch_debug_dump(); }
+namespace vf { void telea_debug_dump(); void telea_window_debug_dump(int B); void telea_window_mw_debug_dump(int B); void unwrap_big_debug_dump(); void unwrap_batch_debug_dump(); }
 #endif
 
 static thread_local std::string g_err;
@@ -235,7 +235,7 @@ void preprocess(vistaf_ftp_handle *hd, const void *frames, int format, int nfram
             } else {
                 if (timed && mode == 1) hipEventRecord(hd->ev[ST_INPAINT], st);
                 if (mode != 1) only = launch_inpaint_window(hd->img, seq_mask, range, hd->inpaint_win_scratch, B, h, w, st, timed ? hd->ev[ST_INPAINT] : nullptr,
-                                                               hd->tiers.telea_two_tier != 0);
+                                                               hd->tiers.telea_two_tier != 0, hd->tiers.telea_mw != 0);
                 launch_inpaint_telea(hd->img, seq_mask, range, hd->inpaint_scratch, hd->status, only, B, h, w, st);
             }
         }
@@ -627,7 +627,7 @@ static int post_demod(vistaf_ftp_handle *hd, int B, float *d_height_mm, uint8_t 
         {
             const int range = std::min(100, std::max(1, cv_round((double)c.inpaint_radius)));
             const int32_t *only = nullptr;
-            if (hd->tiers.inpaint != 1) only = launch_inpaint_window(hd->z0, hd->hole_cand, range, hd->inpaint_win_scratch, B, h, w, st, nullptr, hd->tiers.telea_two_tier != 0);
+            if (hd->tiers.inpaint != 1) only = launch_inpaint_window(hd->z0, hd->hole_cand, range, hd->inpaint_win_scratch, B, h, w, st, nullptr, hd->tiers.telea_two_tier != 0, hd->tiers.telea_mw != 0);
             launch_inpaint_telea(hd->z0, hd->hole_cand, range, hd->inpaint_scratch, hd->status, only, B, h, w, st);
         }
         launch_hole_merge(hd->hmap, hd->reliable, hd->hole_cand, hd->z0, hd->out_rel, B, P, st);
@@ -670,7 +670,7 @@ static int post_demod(vistaf_ftp_handle *hd, int B, float *d_height_mm, uint8_t 
         for (int i = 0; i < ST_COUNT; i++) hipEventElapsedTime(&hd->stage_ms[i], hd->ev[i], hd->ev[i + 1]);
     }
 #ifdef VISTAF_DEBUG
-    if (getenv("VISTAF_TELEA_DBG")) { hipStreamSynchronize(st); telea_debug_dump(); telea_window_debug_dump(B); unwrap_big_debug_dump(); unwrap_batch_debug_dump(); }
+    if (getenv("VISTAF_TELEA_DBG")) { hipStreamSynchronize(st); telea_debug_dump(); telea_window_debug_dump(B); telea_window_mw_debug_dump(B); unwrap_big_debug_dump(); unwrap_batch_debug_dump(); }
 #endif
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VISTAF_E_HIP, std::string("launch: ") + hipGetErrorString(e));
@@ -805,6 +805,7 @@ int vistaf_ftp_test_set(vistaf_ftp_handle *hd, const char *name, int value)
     else if (n == "chamfer_twopass") hd->tiers.chamfer_twopass = value != 0;
     else if (n == "telea_two_tier") hd->tiers.telea_two_tier = value != 0;
     else if (n == "fit_capped") hd->tiers.fit_capped = value != 0;
+    else if (n == "telea_mw") hd->tiers.telea_mw = value != 0;
     else if (n == "keep_planes") hd->keep_planes = value != 0;
     else return fail(VISTAF_E_INVALID, "unknown test hook or value: " + n);
     return 0;

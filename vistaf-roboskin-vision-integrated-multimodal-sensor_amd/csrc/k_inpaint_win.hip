@@ -218,55 +218,9 @@ __device__ __attribute__((always_inline)) inline bool wn_march(float *__restrict
     // ---- pass 1: outside T field (icvCalcFMM, negate); seeds pop first in raster order, then the queue.
     // States here are those of OpenCV's `out` mask: ring = INSIDE, hole and everything else KNOWN.
     {
-        const TeleaOutsideConsts oc = telea_outside_consts(lane, ww);
-        const uint32_t magic_ww = (uint32_t)(0x100000000ull / (unsigned)ww) + 1u;        // cell / ww == umulhi(cell, magic) for cell < 2^16
-        // seeds (raster order): up to 4 per step out of the current 64-cell chunk
+        FmmFlagState fst{t, f};
         WSTAMP(3);
-        for (int base = 0; base < cells && !q.ovf; base += 64) {
-            const int li = base + lane;
-            unsigned long long pend = __ballot(li < cells && (f[li] & W_SEED));
-            while (pend && !q.ovf) {
-                int cand[4];
-                unsigned long long rest = pend;
-#pragma unroll
-                for (int k = 0; k < 4; k++) { cand[k] = base + (int)(__ffsll((long long)rest) - 1); rest &= rest - 1ull; }    // ffs(0) - 1 = -1: masked by n
-                const int np = __popcll(pend);
-                const uint32_t candT[4] = {0u, 0u, 0u, 0u};
-                const int m = telea_pop_outside4(win, oc, cand, candT, telea_outside_prefix(cand, np < 4 ? np : 4, ww, magic_ww), true, lane,
-                                                 [](int) {}, [&](float T_, int idx_) { wq_push<false>(q, T_, idx_, lane); });
-                pend &= pend - 1ull;
-                if (m > 1) pend &= pend - 1ull;
-                if (m > 2) pend &= pend - 1ull;
-                if (m > 3) pend &= pend - 1ull;
-                np1 += m;
-                ns1++;
-            }
-        }
-        // queue: the next <= 4 entries in order are the first words of the cold run once no hot key precedes them
-        while (!q.ovf) {
-            int cold_n = q.tail - q.head;
-            if (cold_n == 0 && q.nh == 0) break;
-            const int g = lane >> 4;
-            unsigned long long wv = g < cold_n ? q.e[q.head + g] : 0ull;
-            const uint32_t t3 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wv >> 32), 48);
-            if (q.nh > 0 && (cold_n < 4 || q.h0 < t3)) {
-                wq_merge<false>(q, lane);
-                cold_n = q.tail - q.head;
-                wv = g < cold_n ? q.e[q.head + g] : 0ull;
-            }
-            if (q.ovf) break;
-            const int n = cold_n < 4 ? cold_n : 4;
-            int cand[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) cand[k] = __builtin_amdgcn_readlane((int)(uint32_t)wv, 16 * k);
-            uint32_t candT[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) candT[k] = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wv >> 32), 16 * k);
-            const int m = telea_pop_outside4(win, oc, cand, candT, telea_outside_prefix(cand, n, ww, magic_ww), false, lane,
-                                             [&](int mc) { q.head += mc; }, [&](float T_, int idx_) { wq_push<false>(q, T_, idx_, lane); });
-            np1 += m;
-            ns1++;
-        }
+        telea_fmm_pass(fst, q, f, cells, ww, lane, np1, ns1);
     }
     WSTAMP(4);
     // negate T where the outside pass ran; switch the state bits to the march's flags (hole = INSIDE, rest KNOWN)
@@ -428,7 +382,7 @@ size_t inpaint_win_scratch_bytes(int B) { return (size_t)B * 5 * sizeof(int32_t)
 
 // box scratch: [4][B] bbox planes + [B] fallback flags.  Returns the device pointer of the fallback flags.
 int32_t *launch_inpaint_window(float *img, const uint8_t *bad, int range, void *scratch, int B, int h, int w, hipStream_t st, hipEvent_t ev_march,
-                               bool two_tier)
+                               bool two_tier, bool mw)
 {
     int32_t *box = (int32_t *)scratch, *fb = box + 4 * (size_t)B;
     (void)hipMemsetAsync(box, 0x7f, (size_t)B * 8, st);
@@ -441,7 +395,12 @@ int32_t *launch_inpaint_window(float *img, const uint8_t *bad, int range, void *
     ensure_dyn_lds(lds_once, (const void *)k_telea_window, 160 * 1024);
     ensure_dyn_lds(lds_once_retry, (const void *)k_telea_window_retry, 160 * 1024);
     if (ev_march) (void)hipEventRecord(ev_march, st);     // stage timing: the march starts here (the bbox pass belongs to the mask stage)
-    if (two_tier) {
+    if (mw && inpaint_window_mw_supported(range)) {
+        // first tier: one 16-wave workgroup per frame (k_inpaint_mw.hip); what it hands back goes to the full-size single-wave march
+        launch_telea_window_mw(img, bad, box, fb, range, B, h, w, st);
+        hipLaunchKernelGGL(k_telea_window_retry, dim3(std::min(B, WN2_GRID)), dim3(64), lds_bytes(WN_CELLS, WN_QCAP), st, img, bad, box, fb, range, B, h, w,
+                           WN_CELLS, WN_QCAP);
+    } else if (two_tier) {
         hipLaunchKernelGGL(k_telea_window, dim3(B), dim3(64), lds_bytes(WN1_CELLS, WN1_QCAP), st, img, bad, box, fb, range, B, h, w, WN1_CELLS, WN1_QCAP);
         hipLaunchKernelGGL(k_telea_window_retry, dim3(std::min(B, WN2_GRID)), dim3(64), lds_bytes(WN_CELLS, WN_QCAP), st, img, bad, box, fb, range, B, h, w,
                            WN_CELLS, WN_QCAP);

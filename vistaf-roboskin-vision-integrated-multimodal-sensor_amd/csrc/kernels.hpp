@@ -15,6 +15,7 @@ struct Tiers {
     int chamfer_twopass = 0;    // 1: force the one-wave two-pass chamfer even where the LDS closed form applies
     int fit_capped = 1;        // 1: register-capped column polyfit (fits on a CU next to a march / flood wave); 0: 128-VGPR variant
     int telea_two_tier = 1;     // 1: 111 KB first tier of the window march + full-size retry of the frames it hands back; 0: full size only
+    int telea_mw = 1;           // 1: the 16-wave window kernel (ordering pass + dataflow fills, k_inpaint_mw.hip) as first tier, single-wave tiers behind it; 0: single-wave tiers only
 };
 
 struct RowSpanSE {      // structuring element as per-row x spans (cv::getStructuringElement ELLIPSE)
@@ -96,8 +97,11 @@ void launch_inpaint_telea(float *img, const uint8_t *bad, int range, void *scrat
 
 // ---- k_inpaint_win.hip (LDS-resident window kernel; returns the per-frame fallback flags for launch_inpaint_telea)
 size_t inpaint_win_scratch_bytes(int B);
+// ---- k_inpaint_mw.hip (16 waves per frame: ordering pass, then the estimates as a dataflow; flags the frames it cannot take in fb[])
+bool inpaint_window_mw_supported(int range);
+void launch_telea_window_mw(float *img, const uint8_t *bad, const int32_t *box, int32_t *fb, int range, int B, int h, int w, hipStream_t st);
 int32_t *launch_inpaint_window(float *img, const uint8_t *bad, int range, void *scratch, int B, int h, int w, hipStream_t st,
-                               hipEvent_t ev_march = nullptr, bool two_tier = true);
+                               hipEvent_t ev_march = nullptr, bool two_tier = true, bool mw = true);
 
 // ---- k_inpaint_cl.hip (cluster-parallel front end; leaves oversized clusters in *bad_big_out) ----------
 size_t inpaint_cl_scratch_bytes_per_frame(int h, int w);

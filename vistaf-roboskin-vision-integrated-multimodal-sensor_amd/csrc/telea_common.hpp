@@ -343,27 +343,57 @@ __device__ inline int telea_outside_prefix(const int (&cells)[4], int n, int ww,
     }
     return m;
 }
+// Where an FMM pass keeps its states.  The pass itself (pop the smallest (T, push order), give every INSIDE 4-neighbour its T, push it) is
+// the same for the outside ring and for the hole: only "which cells are still INSIDE" and what a fill records differ.
+//  * FmmFlagState: OpenCV's `out` flags in the window's flag bytes (outside pass: ring = INSIDE, hole and everything else KNOWN).
+//  * FmmOrderState: the march over the hole WITHOUT its estimator.  T, the pop order and the flag history of cv::inpaint's march depend on
+//    the mask only (FastMarching_solve reads f and t, never the image), so this pass fixes T of every hole pixel and the sequence in which
+//    the march fills them; the estimates are then evaluated in any order that respects their data dependences (k_inpaint_mw.hip).
+//    fi[cell]: 0xFFFF = hole pixel not filled yet (INSIDE), 0xFFFE = not a hole pixel, otherwise the fill's number; list[k] = cell of fill k.
+constexpr uint16_t FI_INSIDE = 0xFFFFu, FI_NOHOLE = 0xFFFEu;
+struct FmmFlagState {
+    float *t;
+    uint8_t *f;
+    __device__ __attribute__((always_inline)) bool inside(int c) const { return (f[c] & W_ST) == W_INSIDE; }
+    __device__ __attribute__((always_inline)) void popped(int p, bool seed) const { f[p] = (uint8_t)(seed ? (W_SEED | W_CHANGE) : W_CHANGE); }   // ring pixels carry no other bit that matters
+    __device__ __attribute__((always_inline)) void filled(int pn, float T, int) const { t[pn] = T; f[pn] = W_BAND; }
+    __device__ __attribute__((always_inline)) void advance(int) {}
+};
+struct FmmOrderState {
+    float *t;
+    uint16_t *fi, *list;
+    int n, cap;                 // fills so far (wave-uniform), capacity of list
+    __device__ __attribute__((always_inline)) bool inside(int c) const { return fi[c] == FI_INSIDE; }
+    __device__ __attribute__((always_inline)) void popped(int, bool) const {}        // KNOWN or BAND: the pass only asks "INSIDE?"
+    __device__ __attribute__((always_inline)) void filled(int pn, float T, int ord) const
+    {
+        const int k = n + ord;
+        t[pn] = T; fi[pn] = (uint16_t)(k < cap ? k : cap);        // (beyond the capacity the frame is handed back; any value != INSIDE keeps the pass going)
+        if (k < cap) list[k] = (uint16_t)pn;
+    }
+    __device__ __attribute__((always_inline)) void advance(int cnt) { n += cnt; }
+};
+
 // cellT = the float bits of the candidates' T (all 0 for the seeds, which never wait for a push); commit(k) removes the k entries
 // from the queue.  Returns the number of entries popped (1..m).
-template <class Commit, class Push>
-__device__ __attribute__((always_inline)) inline int telea_pop_outside4(const TeleaWin &win, const TeleaOutsideConsts &oc, const int (&cells)[4],
+template <class State, class Commit, class Push>
+__device__ __attribute__((always_inline)) inline int telea_pop_outside4(State &st, const TeleaOutsideConsts &oc, const int (&cells)[4],
                                                                         const uint32_t (&cellT)[4], int m, bool seed, int lane, Commit commit, Push push)
 {
-    float *t = win.t;
-    uint8_t *f = win.f;
+    float *t = st.t;
     const int dn = oc.dn, d1 = oc.d1, d2 = oc.d2;
     const int g = lane >> 4;
     const int p = g == 0 ? cells[0] : g == 1 ? cells[1] : g == 2 ? cells[2] : cells[3];
     const int pn = p + dn;
-    const bool ok = g < m && (f[pn] & W_ST) == W_INSIDE;
+    const bool ok = g < m && st.inside(pn);
     unsigned long long okb = __ballot(ok);
     if (okb) {
         float dist = 0.f;
         if (ok) {
             const int p1 = pn + d1, p2 = pn + d2;
             float a11 = t[p1], a22 = t[p2];
-            uint8_t f1 = f[p1], f2 = f[p2];           // p itself may be among them: BAND now, CHANGE after the pop -- not INSIDE either way
-            dist = wn_solve(a11, a22, (f1 & W_ST) != W_INSIDE, (f2 & W_ST) != W_INSIDE);
+            const bool k1 = !st.inside(p1), k2 = !st.inside(p2);           // p itself may be among them: BAND now, CHANGE after the pop -- not INSIDE either way
+            dist = wn_solve(a11, a22, k1, k2);
         }
         float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dist), 0xB1, 0xf, 0xf, false)); dist = o < dist ? o : dist;
         o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dist), 0x4E, 0xf, 0xf, false)); dist = o < dist ? o : dist;
@@ -389,11 +419,12 @@ __device__ __attribute__((always_inline)) inline int telea_pop_outside4(const Te
             okb &= m >= 4 ? ~0ull : (1ull << (16 * m)) - 1ull;
         }
         commit(m);                            // the m entries leave the queue before their pushes enter it
-        if (g < m && (lane & 15) == 0) f[p] = (uint8_t)(seed ? (W_SEED | W_CHANGE) : W_CHANGE);   // ring pixels carry no other bit that matters
+        if (g < m && (lane & 15) == 0) st.popped(p, seed);
         // the new band pixels are distinct cells (four neighbours of a pop; pops of a batch are >= 4 apart): their quad leaders store
         // T and the state together; only the queue insertions are ordered
         unsigned long long pb = okb & 0x1111111111111111ull;
-        if ((pb >> lane) & 1ull) { t[pn] = dist; f[pn] = W_BAND; }
+        if ((pb >> lane) & 1ull) st.filled(pn, dist, __popcll(pb & ((1ull << lane) - 1ull)));     // numbered in push order
+        st.advance(__popcll(pb));
         // pushes in the order of the sequential loop: pop by pop, neighbour by neighbour = ascending lane among the quad leaders
         while (pb) {
             const int l = __ffsll((long long)pb) - 1;
@@ -402,9 +433,64 @@ __device__ __attribute__((always_inline)) inline int telea_pop_outside4(const Te
         }
     } else {
         commit(m);
-        if (g < m && (lane & 15) == 0) f[p] = (uint8_t)(seed ? (W_SEED | W_CHANGE) : W_CHANGE);
+        if (g < m && (lane & 15) == 0) st.popped(p, seed);
     }
     return m;
+}
+
+// One whole FMM pass on a window: the seeds (cells with W_SEED in the flag bytes, T = 0) pop first in raster order, up to four per step out
+// of the current 64-cell chunk, then the queue -- the next <= 4 entries in order are the first words of the cold run once no hot key
+// precedes them.  np / ns count pops / steps (diagnostics).
+template <class State>
+__device__ __attribute__((always_inline)) inline void telea_fmm_pass(State &st, WQ &q, const uint8_t *f, int cells, int ww, int lane,
+                                                                     unsigned long long &np, unsigned long long &ns)
+{
+    const TeleaOutsideConsts oc = telea_outside_consts(lane, ww);
+    const uint32_t magic_ww = (uint32_t)(0x100000000ull / (unsigned)ww) + 1u;        // cell / ww == umulhi(cell, magic) for cell < 2^16
+    for (int base = 0; base < cells && !q.ovf; base += 64) {
+        const int li = base + lane;
+        unsigned long long pend = __ballot(li < cells && (f[li] & W_SEED));
+        while (pend && !q.ovf) {
+            int cand[4];
+            unsigned long long rest = pend;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { cand[k] = base + (int)(__ffsll((long long)rest) - 1); rest &= rest - 1ull; }    // ffs(0) - 1 = -1: masked by n
+            const int npend = __popcll(pend);
+            const uint32_t candT[4] = {0u, 0u, 0u, 0u};
+            const int m = telea_pop_outside4(st, oc, cand, candT, telea_outside_prefix(cand, npend < 4 ? npend : 4, ww, magic_ww), true, lane,
+                                             [](int) {}, [&](float T_, int idx_) { wq_push<false>(q, T_, idx_, lane); });
+            pend &= pend - 1ull;
+            if (m > 1) pend &= pend - 1ull;
+            if (m > 2) pend &= pend - 1ull;
+            if (m > 3) pend &= pend - 1ull;
+            np += m;
+            ns++;
+        }
+    }
+    while (!q.ovf) {
+        int cold_n = q.tail - q.head;
+        if (cold_n == 0 && q.nh == 0) break;
+        const int g = lane >> 4;
+        unsigned long long wv = g < cold_n ? q.e[q.head + g] : 0ull;
+        const uint32_t t3 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wv >> 32), 48);
+        if (q.nh > 0 && (cold_n < 4 || q.h0 < t3)) {
+            wq_merge<false>(q, lane);
+            cold_n = q.tail - q.head;
+            wv = g < cold_n ? q.e[q.head + g] : 0ull;
+        }
+        if (q.ovf) break;
+        const int n = cold_n < 4 ? cold_n : 4;
+        int cand[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) cand[k] = __builtin_amdgcn_readlane((int)(uint32_t)wv, 16 * k);
+        uint32_t candT[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) candT[k] = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wv >> 32), 16 * k);
+        const int m = telea_pop_outside4(st, oc, cand, candT, telea_outside_prefix(cand, n, ww, magic_ww), false, lane,
+                                         [&](int mc) { q.head += mc; }, [&](float T_, int idx_) { wq_push<false>(q, T_, idx_, lane); });
+        np += m;
+        ns++;
+    }
 }
 
 #ifdef VISTAF_DEBUG
@@ -579,6 +665,58 @@ __device__ __attribute__((always_inline)) inline int telea_pop_march(const Telea
         push(dist, pi);
     }
     return nfill;
+}
+
+// The estimate of ONE hole pixel pi whose T the ordering pass (FmmOrderState) has already fixed: the fill block of telea_pop_march without
+// the quadrant solve and the push, same operations in the same order (so the value carries the same bits).  The caller guarantees that
+// every fill within Chebyshev distance range + 1 of pi runs in march order (the block reads flags, T and image values that far out):
+// then "flag != INSIDE" in the live flag bytes is exactly the flag history cv::inpaint's march would have seen at this fill.
+// (T of cells that are still INSIDE already holds its final value instead of 1e6; every use of it is masked by the cell's flag.)
+template <int NS>
+__device__ __attribute__((always_inline)) inline void telea_fill_known_T(const TeleaWin &win, const TeleaMarchConsts &mc, int pi, int lane)
+{
+    static_assert(NS > 0 && NS <= 64, "one estimator chunk");
+    float *t = win.t, *im = win.im;
+    uint8_t *f = win.f;
+    const int ww = win.ww, d4 = mc.d4;
+    const uint8_t f4 = f[pi + d4];
+    const float t4 = t[pi + d4];
+    const float tcl = t[pi];
+    const int pk = pi + mc.off[0];
+    const uint8_t f0 = f[pk], fr = f[pk + 1], fl = f[pk - 1], fd = f[pk + ww], fu = f[pk - ww];
+    const float tk = t[pk];
+    const int sk = (fu >> 4) & 1, sK = (fd >> 4) & 1, sl = (fl >> 4) & 1, sL = (fr >> 4) & 1;
+    const int rowm = pk + (sk ? ww : 0);
+    const float vC = im[rowm + sl], vA = im[rowm + 1 - sL], vB = im[rowm + sl - 1], vD = im[rowm - sL];
+    const float vE = im[pk + (sK ? 0 : ww) + sl], vF = im[rowm - ww + sl], vG = im[pk - (sK ? ww : 0) + sl];
+    const float tu = wn_lane_f(t4, 0), tl = wn_lane_f(t4, 1), td = wn_lane_f(t4, 2), tr = wn_lane_f(t4, 3);
+    const float tc = wn_lane_f(tcl, 0);
+    unsigned kv = (unsigned)__ballot((f4 & W_ST) != W_INSIDE) & 0xf;
+    asm volatile("" : "+v"(kv));
+    const bool ku = kv & 1, kl = kv & 2, kd = kv & 4, kr = kv & 8;
+    const float gx2 = __fmul_rn(__fsub_rn(tr, tl), 0.5f), gxr = __fsub_rn(tr, tc), gxl = __fsub_rn(tc, tl);
+    const float gy2 = __fmul_rn(__fsub_rn(td, tu), 0.5f), gyd = __fsub_rn(td, tc), gyu = __fsub_rn(tc, tu);
+    const float gtx_r = kl ? gx2 : gxr, gtx_n = kl ? gxl : 0.f, gtx = kr ? gtx_r : gtx_n;
+    const float gty_d = ku ? gy2 : gyd, gty_n = ku ? gyu : 0.f, gty = kd ? gty_d : gty_n;
+    const float rx = mc.rx[0], ry = mc.ry[0];
+    const bool use = (int)mc.on[0] & (int)((f0 & W_BORDER) == 0) & (int)((f0 & W_ST) != W_INSIDE);
+    const float lev = telea_lev(tk, tc);
+    float dir = __fadd_rn(__fmul_rn(rx, gtx), __fmul_rn(ry, gty));
+    dir = fabsf(dir) <= 0.01f ? 0.000001f : dir;
+    const float wgt = fabsf(__fmul_rn(__fmul_rn(mc.dstw[0], lev), dir));
+    const bool nr = (fr & W_ST) != W_INSIDE, nl = (fl & W_ST) != W_INSIDE, nd = (fd & W_ST) != W_INSIDE, nu = (fu & W_ST) != W_INSIDE;
+    const float ix2 = __fmul_rn(__fsub_rn(vA, vB), 2.0f), ixr = __fsub_rn(vA, vC), ixl = __fsub_rn(vD, vB);
+    const float iy2 = __fmul_rn(__fsub_rn(vE, vF), 2.0f), iyd = __fsub_rn(vE, vC), iyu = __fsub_rn(vG, vF);
+    const float gix_r = nl ? ix2 : ixr, gix_n = nl ? ixl : 0.f, gix = nr ? gix_r : gix_n;
+    const float giy_d = nu ? iy2 : iyd, giy_n = nu ? iyu : 0.f, giy = nd ? giy_d : giy_n;
+    const float z = 0.f;
+    float Ia = use ? __fmul_rn(wgt, vC) : z;
+    float Jx = use ? -__fmul_rn(wgt, __fmul_rn(gix, rx)) : z;
+    float Jy = use ? -__fmul_rn(wgt, __fmul_rn(giy, ry)) : z;
+    float s = use ? wgt : z;
+    wn_seq_sum4<NS>(Ia, Jx, Jy, s, 1.0e-20f, lane);
+    const float val = telea_estimate(Ia, Jx, Jy, s);
+    if (lane == 0) { im[pi] = val; f[pi] = (uint8_t)(W_HOLE | W_BAND); }
 }
 
 }  // namespace vf
