@@ -399,10 +399,27 @@ static float fmm_solve(int i1, int j1, int i2, int j2, const uint8_t *f, const f
 static float min4f(float a, float b, float c, float d)
 { a = a < b ? a : b; c = c < d ? c : d; return a < c ? a : c; }
 
+/* optional log of the march's fill sequence (diagnostics and the test of the GPU's ordering pass): fill number per pixel, -1 = not filled */
+static int32_t *g_fill_index = NULL;
+static int32_t g_fill_count = 0;
+/* optional log of both FMM passes' pops: rows (pass, i, j) in padded coordinates and the popped T */
+static int32_t *g_pop_log = NULL;
+static float *g_pop_T = NULL;
+static int32_t g_pop_cap = 0, g_pop_count = 0;
+static void log_pop(int pass, int i, int j, float T)
+{
+    if (g_pop_log && g_pop_count < g_pop_cap) {
+        g_pop_log[3 * g_pop_count] = pass; g_pop_log[3 * g_pop_count + 1] = i; g_pop_log[3 * g_pop_count + 2] = j;
+        g_pop_T[g_pop_count] = T;
+    }
+    g_pop_count++;
+}
+
 static void calc_fmm(uint8_t *f, float *t, pq_t *q, int er, int ec, int negate)
 {
     int ii, jj;
     while (pq_pop(q, &ii, &jj)) {
+        log_pop(0, ii, jj, t[(size_t)ii * ec + jj]);
         f[(size_t)ii * ec + jj] = (uint8_t)(negate ? F_CHANGE : F_KNOWN);
         for (int k = 0; k < 4; k++) {
             int i = ii, j = jj;
@@ -421,10 +438,6 @@ static void calc_fmm(uint8_t *f, float *t, pq_t *q, int er, int ec, int negate)
         for (size_t p = 0; p < (size_t)er * ec; p++)
             if (f[p] == F_CHANGE) { f[p] = F_KNOWN; t[p] = -t[p]; }
 }
-
-/* optional log of the march's fill sequence (diagnostics and the test of the GPU's ordering pass): fill number per pixel, -1 = not filled */
-static int32_t *g_fill_index = NULL;
-static int32_t g_fill_count = 0;
 
 void cvl_inpaint_telea_f32(const float *src, const uint8_t *inpaint_mask, float *dst, int h, int w, double radius)
 {
@@ -481,6 +494,7 @@ void cvl_inpaint_telea_f32(const float *src, const uint8_t *inpaint_mask, float 
     uint8_t *f = mask;
     int ii, jj;
     while (pq_pop(&heap, &ii, &jj)) {
+        log_pop(1, ii, jj, t[(size_t)ii * ec + jj]);
         f[(size_t)ii * ec + jj] = F_KNOWN;
         for (int q = 0; q < 4; q++) {
             int i = ii, j = jj;
@@ -556,6 +570,15 @@ void cvl_inpaint_telea_f32(const float *src, const uint8_t *inpaint_mask, float 
         }
     }
     free(heap.e); free(outq.e); free(t); free(mask); free(band); free(out);
+}
+
+/* the same call, also logging every pop of the outside pass (pass 0) and of the march (pass 1): returns the number of pops */
+int cvl_inpaint_telea_f32_pops(const float *src, const uint8_t *inpaint_mask, float *dst, int32_t *pop_log, float *pop_T, int cap, int h, int w, double radius)
+{
+    g_pop_log = pop_log; g_pop_T = pop_T; g_pop_cap = cap; g_pop_count = 0;
+    cvl_inpaint_telea_f32(src, inpaint_mask, dst, h, w, radius);
+    g_pop_log = NULL; g_pop_T = NULL;
+    return g_pop_count;
 }
 
 /* the same call, also reporting the order in which the march filled the hole pixels (0, 1, 2, ...; -1 elsewhere); returns the count */

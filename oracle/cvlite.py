@@ -169,6 +169,21 @@ def inpaint_telea_order(src, mask, radius: float):
     return dst, order
 
 
+def inpaint_telea_pops(src, mask, radius: float, cap: int = 1 << 20):
+    """inpaint_telea plus the pop log of its two FMM passes: (dst, rows int32 [n, 3] = (pass, i, j) in padded coordinates, T float32 [n])."""
+    src = _f32(src)
+    m = _u8(mask)
+    dst = np.empty_like(src)
+    log = np.empty((cap, 3), np.int32)
+    tt = np.empty(cap, np.float32)
+    h, w = src.shape
+    f = lib().cvl_inpaint_telea_f32_pops
+    f.restype = ctypes.c_int
+    n = f(_p(src), _p(m), _p(dst), _p(log), _p(tt), ctypes.c_int(cap), ctypes.c_int(h), ctypes.c_int(w), ctypes.c_double(radius))
+    n = min(n, cap)
+    return dst, log[:n].copy(), tt[:n].copy()
+
+
 def unwrap_quality_guided(wrapped, mask, quality, want_tree: bool = False):
     """shape_ftp.unwrap_quality_guided (shape_ftp.py:1043-1080), exact heap order."""
     wrapped = _f32(wrapped)

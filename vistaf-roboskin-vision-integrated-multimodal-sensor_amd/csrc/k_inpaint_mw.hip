@@ -1,22 +1,27 @@
 // cv2.inpaint(INPAINT_TELEA) on the frame's hole window -- one WORKGROUP of 16 waves per frame (shape_ftp.py:652-666).
 //
-// The single-wave window kernel (k_inpaint_win.hip) replays cv::inpaint's march pop by pop: every fill waits for the previous pixel's
-// estimator although the estimator never decides what pops next.  What the march does in which order depends on the mask only
-// (FastMarching_solve reads the flags and T, never the image), so this kernel splits it:
-//   phase 0  all waves   load the window, build band / outside ring (the same cells, states and raster order as the single-wave kernel);
-//   phase 1  wave 0      outside T field (icvCalcFMM with `negate`), states in the flag bytes;
-//            wave 1      the march over the hole WITHOUT estimator (FmmOrderState): T of every hole pixel and the fill sequence.
-//                        The two passes touch disjoint cells (ring cells have no hole neighbour, hole pixels no ring neighbour; the band
-//                        pixels between them keep T = 0 and their seed bit), so they run side by side;
-//   phase 2  all waves   negate the ring's T, switch the flag bytes to the march's states, count for every fill the earlier fills within
-//                        Chebyshev distance range + 1 (the reach of a fill's reads);
-//   phase 3  all waves   the estimates as a dataflow: a fill runs once its counter is 0, then decrements the counters of the later fills in
-//                        reach and queues those that drop to 0.  Any two fills in reach of each other therefore run in march order and see
-//                        each other's stores, fills farther apart commute -- the plane is the sequential march's bit for bit (each fill is
-//                        telea_fill_known_T: the single-wave fill block minus solve and push);
-//   phase 4  all waves   write the hole pixels back.
-// The bench frames have ~1 400 fills per frame in ~200 dependence levels (tools/telea_dag.py), up to 17 fills wide.
-// Frames whose window, queues or fill list do not fit are flagged in fb[] for the full-size single-wave tier (k_telea_window_retry).
+// The single-wave window kernel (k_inpaint_win.hip) replays cv::inpaint pop by pop.  Two facts let a whole workgroup work on one frame
+// without changing a bit of the result:
+//
+//  (1) What the march does in which order depends on the mask only: FastMarching_solve reads the flags and T, never the image.  So T of
+//      every hole pixel and the sequence of the fills can be fixed first (an FMM pass without estimator, like the outside pass), and the
+//      estimates then run as a DATAFLOW: a fill reads flags, T and image values within Chebyshev distance range + 1 of its pixel, so two
+//      fills in reach of each other must run in march order, and fills farther apart commute.
+//
+//  (2) An FMM pass itself is a sequence of GENERATIONS.  A pop at T_p only pushes values T >= T_p + 0.7071 (every non-INSIDE 4-neighbour
+//      of a pixel that is filled now is still in the queue -- had it popped earlier, that pop would have filled the pixel -- so both
+//      arguments of the solve are >= T_p, and min + (|d| + sqrt(2 - d^2)) / 2 >= min + sqrt(1/2)).  Hence the entries with
+//      T < T_head + 0.70 pop next, in their present (T, push order), whatever is pushed meanwhile: a generation.  Inside a generation
+//      the order is known up front, a pop writes within Manhattan distance 1 of its pixel and reads within 2, so pops at distance >= 4
+//      commute and the others run in queue order -- again a dataflow.  The pushes of a generation carry (generation, parent's rank,
+//      neighbour) as push order, which is the order the one-at-a-time loop would have pushed them in.
+//      The bench frames: 6 generations for the outside pass, 7-9 for the hole, ~2 000 pops each in ~160 / ~230 dependence levels
+//      (the band pixels' raster-order chains make up 100 of them), ~1 400 fills in ~200 levels (tools/telea_dag.py).
+//
+// Phases (all 16 waves unless noted): window flags + ring | outside pass (icvCalcFMM with negate), generation by generation |
+// the march's ordering pass over the hole, generation by generation | image load, negate, dependence counters of the fills |
+// the estimates (telea_fill_known_T: the single-wave fill block minus solve and push) from a ready queue | write back.
+// Frames whose window, queues or lists do not fit are flagged in fb[] for the full-size single-wave tier (k_telea_window_retry).
 #include <cstdio>
 #include "kernels.hpp"
 #include <type_traits>
@@ -27,25 +32,279 @@ namespace vf {
 constexpr int MW_WAVES = 16;
 constexpr int MW_T = MW_WAVES * 64;
 constexpr int MW_CELLS = 10752;     // window cells: 11 B each (T f32, image f32, fill number u16, flags u8)
-constexpr int MW_QCAP = 2048;       // live queue entries of each of the two FMM passes
 constexpr int MW_FILLS = 4096;      // hole pixels per frame
 constexpr int MW_RING_U = 6;
-enum { MWC_FAIL = 0, MWC_NFILL = 1, MWC_HEAD = 2, MWC_TAIL = 3, MWC_N = 16 };
-constexpr size_t MW_LDS = (size_t)MW_QCAP * 16 + (size_t)MW_CELLS * 11 + (size_t)MW_FILLS * 2 + 2 * 64 * 4 + MWC_N * 4;
+constexpr int GP_POOL = 4096;       // pushes of one FMM pass (the pool is append-only: popped entries are blanked)
+constexpr int GP_GEN = 2048;        // entries of one generation
+constexpr int GP_MAXGEN = 32;
+constexpr int GP_CNT = 256;         // chunk counts / bitmap prefix
+// fill-number plane: hole pixel not filled yet / not a hole pixel / filled (number pending) / queued in the current generation with rank r
+constexpr uint16_t FI_INSIDE = 0x3FFFu, FI_NOHOLE = 0x3FFEu, FI_FILLED = 0x3FFDu, FI_PEND = 0x8000u;
+enum { MWC_FAIL = 0, MWC_NFILL, MWC_HEAD, MWC_TAIL, MWC_POOLN, MWC_GENN, MWC_TMIN, MWC_N = 16 };
+constexpr size_t MW_REGION_A = (size_t)GP_POOL * 8;          // FMM: pool; fills: dependence counters u32 + ready queue u16
+constexpr size_t MW_LDS = MW_REGION_A + (size_t)MW_CELLS * 11 + (size_t)MW_FILLS * 2 + GP_CNT * 4 + MWC_N * 4;
 static_assert(MW_LDS <= 160 * 1024, "one CU's LDS");
-static_assert(MW_FILLS * 4 <= MW_QCAP * 8 && MW_FILLS * 2 <= MW_QCAP * 8, "dependence counters / ready queue reuse the FMM queues");
-static_assert(MW_FILLS < FI_NOHOLE, "fill numbers are 16-bit");
+static_assert((size_t)MW_FILLS * 6 <= MW_REGION_A, "dependence counters and ready queue of the fills");
+static_assert((size_t)GP_GEN * (8 + 4 + 2) + GP_GEN * 4 / 8 <= (size_t)MW_CELLS * 4, "generation scratch lives in the image plane until the image is loaded");
+static_assert(MW_FILLS < FI_FILLED && GP_GEN <= 0x800 && MW_CELLS <= 0x4000 && MW_CELLS / 64 <= GP_CNT && GP_GEN * 4 / 32 <= GP_CNT, "field widths");
 
 #ifdef VISTAF_DEBUG
 __device__ unsigned long long g_mw_dbg[1024][16];
 #define MSTAMP(i) do { if (threadIdx.x == 0 && b < 1024) g_mw_dbg[b][i] = __builtin_amdgcn_s_memtime(); } while (0)
-#define MSTAMP_W(i) do { if (lane == 0 && b < 1024) g_mw_dbg[b][i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define MSTAMP(i) do { } while (0)
-#define MSTAMP_W(i) do { } while (0)
 #endif
 
-// phase 3 of one wave: claim the next slot of the ready queue, wait for its fill, estimate, release the fills that waited for it
+struct GenScratch {
+    unsigned long long *pool;       // [GP_POOL] (T bits | generation | parent's rank | neighbour | cell), blank = ~0
+    unsigned long long *gen;        // [GP_GEN] the current generation in pop order
+    uint32_t *dep;                  // [GP_GEN] earlier entries of the generation within Manhattan distance 3 that have not popped yet
+    uint16_t *rq;                   // [GP_GEN] ready queue
+    uint32_t *bitmap;               // [GP_GEN * 4 / 32] fills of the generation by (rank, neighbour)
+    int *cnt;                       // [GP_CNT]
+    int *ctl;
+};
+__device__ inline unsigned long long gp_key(float T, int g, int rank, int nb, int cell)
+{
+    return ((unsigned long long)__float_as_uint(T) << 32) | ((unsigned long long)(((uint32_t)g << 27) | ((uint32_t)rank << 16) | ((uint32_t)nb << 14) | (uint32_t)cell));
+}
+__device__ inline int wave_excl_scan(int v, int lane, int &total)
+{
+    int s = v;
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(s, o, 64); if (lane >= o) s += u; }
+    total = __shfl(s, 63, 64);
+    return s - v;
+}
+
+// the pops of one generation on one wave: claim the next slot of the ready queue, wait for its entry, pop it, release the entries that
+// waited for it.  ORDER: the march's ordering pass (states in the fill-number plane), else the outside pass (states in the flag bytes)
+template <bool ORDER>
+__device__ __attribute__((always_inline)) inline void gp_pop_loop(const GenScratch &S, float *t, uint8_t *f, uint16_t *fi, int M, int g, int wh, int ww,
+                                                                  uint32_t mg_ww, int lane)
+{
+    const TeleaOutsideConsts oc = telea_outside_consts(lane, ww);       // lanes 0..15 = 4 neighbours x 4 quadrants
+    const int nbi = (lane >> 2) & 3;
+    // the 24 cells within Manhattan distance 3, one per lane
+    int ndy = 0, ndx = 0;
+    {
+        int i = lane;
+        const int rows[7] = {1, 3, 5, 6, 5, 3, 1};
+        int dy = -3;
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            if (i >= 0 && i < rows[k]) {
+                const int rad = 3 - (dy < 0 ? -dy : dy);
+                int dx = i - rad;
+                if (dy == 0 && dx >= 0) dx++;              // skip the centre
+                ndy = dy; ndx = dx;
+            }
+            i -= rows[k];
+            dy++;
+        }
+    }
+    const bool non = lane < 24;
+    const int noff = ndy * ww + ndx;
+    auto inside = [&](int c) -> bool { return ORDER ? fi[c] == FI_INSIDE : (f[c] & W_ST) == W_INSIDE; };
+    int *ctl = S.ctl;
+    for (;;) {
+        int s = 0;
+        if (lane == 0) s = atomicAdd(&ctl[MWC_HEAD], 1);
+        s = __builtin_amdgcn_readfirstlane(s);
+        if (s >= M) break;                       // every entry is queued exactly once: slots [0, M) all get one
+        unsigned r;
+        while ((r = ((volatile uint16_t *)S.rq)[s]) == 0xFFFFu) __builtin_amdgcn_s_sleep(1);
+        r = (unsigned)__builtin_amdgcn_readfirstlane((int)r);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int p = (int)((uint32_t)S.gen[r] & 0x3FFFu);
+        const int pn = p + oc.dn;
+        const bool ok = lane < 16 && inside(pn);
+        const unsigned long long okb = __ballot(ok);
+        float dist = 0.f;
+        if (okb) {
+            if (ok) {
+                const int p1 = pn + oc.d1, p2 = pn + oc.d2;
+                const float a11 = t[p1], a22 = t[p2];
+                dist = wn_solve(a11, a22, !inside(p1), !inside(p2));
+            }
+            float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dist), 0xB1, 0xf, 0xf, false)); dist = o < dist ? o : dist;
+            o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dist), 0x4E, 0xf, 0xf, false)); dist = o < dist ? o : dist;
+        }
+        if (lane == 0) {                          // the entry leaves the queue (this also drops its rank mark)
+            if (ORDER) fi[p] = g == 0 ? FI_NOHOLE : FI_FILLED;
+            else { f[p] = (uint8_t)(g == 0 ? (W_SEED | W_CHANGE) : W_CHANGE); fi[p] = FI_NOHOLE; }
+        }
+        const unsigned long long pb = okb & 0x1111ull;
+        if (pb) {
+            const int cnt = __popcll(pb);
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&ctl[MWC_POOLN], cnt);
+            base = __builtin_amdgcn_readfirstlane(base);
+            const bool fits = base + cnt <= GP_POOL;
+            if (!fits && lane == 0) ctl[MWC_FAIL] = 1;
+            if ((pb >> lane) & 1ull) {
+                t[pn] = dist;
+                if (ORDER) fi[pn] = FI_FILLED; else f[pn] = W_BAND;
+                if (fits) S.pool[base + __popcll(pb & ((1ull << lane) - 1ull))] = gp_key(dist, g, (int)r, nbi, pn);
+                if (ORDER) atomicOr(&S.bitmap[(r * 4 + nbi) >> 5], 1u << ((r * 4 + nbi) & 31));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (non) {
+            const int py = (int)__umulhi((uint32_t)p, mg_ww), px = p - py * ww;
+            const int y = py + ndy, x = px + ndx;
+            if (y >= 0 && y < wh && x >= 0 && x < ww) {
+                const unsigned v = fi[p + noff];
+                const unsigned rv = v & 0x7FFFu;
+                if ((v & FI_PEND) && rv > r) {
+                    if (atomicSub(&S.dep[rv], 1u) == 1u) {
+                        const int slot = atomicAdd(&ctl[MWC_TAIL], 1);
+                        ((volatile uint16_t *)S.rq)[slot] = (uint16_t)rv;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// One FMM pass over the window, generation by generation.  Returns false (uniformly) when a capacity was exceeded.
+template <bool ORDER>
+__device__ __attribute__((always_inline)) inline bool gp_pass(const GenScratch &S, float *t, uint8_t *f, uint16_t *fi, uint16_t *flist, int cells, int wh, int ww,
+                                                              uint32_t mg_ww, int tid, int lane, int wave)
+{
+    int *ctl = S.ctl;
+    // generation 0: the band pixels in raster order (T = 0)
+    const int nchunk = (cells + 63) >> 6;
+    for (int ch = wave; ch < nchunk; ch += MW_WAVES) {
+        const int li = ch * 64 + lane;
+        const unsigned long long bal = __ballot(li < cells && (f[li] & W_SEED));
+        if (lane == 0) S.cnt[ch] = __popcll(bal);
+    }
+    if (tid == 0) { ctl[MWC_POOLN] = 0; ctl[MWC_TMIN] = (int)0xFFFFFFFFu; if (ORDER) ctl[MWC_NFILL] = 0; }
+    __syncthreads();
+    if (wave == 0) {
+        int a[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const int ch = lane * 4 + k; a[k] = ch < nchunk ? S.cnt[ch] : 0; sum += a[k]; }
+        int total;
+        int ex = wave_excl_scan(sum, lane, total);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const int ch = lane * 4 + k; if (ch < nchunk) S.cnt[ch] = ex; ex += a[k]; }
+        if (lane == 0) ctl[MWC_GENN] = total;
+    }
+    __syncthreads();
+    int M = ctl[MWC_GENN];
+    if (M > GP_GEN) return false;
+    for (int ch = wave; ch < nchunk; ch += MW_WAVES) {
+        const int li = ch * 64 + lane;
+        const bool sd = li < cells && (f[li] & W_SEED);
+        const unsigned long long bal = __ballot(sd);
+        if (sd) { const int r = S.cnt[ch] + __popcll(bal & ((1ull << lane) - 1ull)); S.gen[r] = gp_key(0.f, 0, r, 0, li); }
+    }
+    __syncthreads();
+
+    for (int g = 0;; g++) {
+        // rank marks, empty ready queue
+        for (int r = tid; r < M; r += MW_T) {
+            const int cell = (int)((uint32_t)S.gen[r] & 0x3FFFu);
+            fi[cell] = (uint16_t)(FI_PEND | r);
+            S.rq[r] = 0xFFFFu;
+        }
+        if (ORDER) for (int i = tid; i < GP_GEN * 4 / 32; i += MW_T) S.bitmap[i] = 0;
+        if (tid == 0) { ctl[MWC_HEAD] = 0; ctl[MWC_TAIL] = 0; ctl[MWC_GENN] = 0; }
+        const int pool_n0 = ctl[MWC_POOLN];
+        __syncthreads();
+        // dependence counters: earlier entries of this generation within Manhattan distance 3
+        for (int r = tid; r < M; r += MW_T) {
+            const int cell = (int)((uint32_t)S.gen[r] & 0x3FFFu);
+            const int py = (int)__umulhi((uint32_t)cell, mg_ww), px = cell - py * ww;
+            uint32_t c = 0;
+#pragma unroll
+            for (int dy = -3; dy <= 3; dy++) {
+                const int rad = 3 - (dy < 0 ? -dy : dy);
+                const bool yin = py + dy >= 0 && py + dy < wh;
+#pragma unroll
+                for (int dx = -rad; dx <= rad; dx++) {
+                    if (dy == 0 && dx == 0) continue;
+                    const bool in = yin && px + dx >= 0 && px + dx < ww;
+                    const unsigned v = fi[in ? cell + dy * ww + dx : cell];
+                    c += (in && (v & FI_PEND) && (v & 0x7FFFu) < (unsigned)r) ? 1u : 0u;
+                }
+            }
+            S.dep[r] = c;
+            if (c == 0) { const int slot = atomicAdd(&ctl[MWC_TAIL], 1); S.rq[slot] = (uint16_t)r; }
+        }
+        __syncthreads();
+        gp_pop_loop<ORDER>(S, t, f, fi, M, g, wh, ww, mg_ww, lane);
+        __syncthreads();
+        if (ctl[MWC_FAIL]) return false;
+        const int pool_n = ctl[MWC_POOLN];
+        if (ORDER) {
+            // number this generation's fills in push order = by (parent's rank, neighbour)
+            if (wave == 0) {
+                int a[4], sum = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) { a[k] = __popc(S.bitmap[lane * 4 + k]); sum += a[k]; }
+                int total;
+                int ex = wave_excl_scan(sum, lane, total);
+#pragma unroll
+                for (int k = 0; k < 4; k++) { S.cnt[lane * 4 + k] = ex; ex += a[k]; }
+            }
+            __syncthreads();
+            const int nf0 = ctl[MWC_NFILL];
+            for (int i = pool_n0 + tid; i < pool_n; i += MW_T) {
+                const uint32_t lo = (uint32_t)S.pool[i];
+                const unsigned bi = (lo >> 14) & 0x1FFFu;                  // rank * 4 + neighbour
+                const int num = nf0 + S.cnt[bi >> 5] + __popc(S.bitmap[bi >> 5] & ((1u << (bi & 31)) - 1u));
+                if (num < MW_FILLS) flist[num] = (uint16_t)(lo & 0x3FFFu);
+            }
+            __syncthreads();
+            if (tid == 0) ctl[MWC_NFILL] = nf0 + (pool_n - pool_n0);
+        }
+        // the next generation: everything below T_head + 0.70
+        {
+            uint32_t mn = 0xFFFFFFFFu;
+            for (int i = tid; i < pool_n; i += MW_T) { const uint32_t tb = (uint32_t)(S.pool[i] >> 32); mn = tb < mn ? tb : mn; }
+            for (int o = 32; o; o >>= 1) { const uint32_t u = (uint32_t)__shfl_xor((int)mn, o, 64); mn = u < mn ? u : mn; }
+            if (lane == 0 && mn != 0xFFFFFFFFu) atomicMin((unsigned int *)&ctl[MWC_TMIN], mn);
+        }
+        __syncthreads();
+        const uint32_t tmin = (uint32_t)ctl[MWC_TMIN];
+        if (tmin == 0xFFFFFFFFu) break;                                   // queue empty: the pass is complete
+        if (g + 1 >= GP_MAXGEN) return false;
+        const uint32_t thr = __float_as_uint(__uint_as_float(tmin) + 0.70f);
+        for (int i = tid; i < pool_n; i += MW_T) {
+            const unsigned long long k = S.pool[i];
+            if ((uint32_t)(k >> 32) < thr) {
+                const int slot = atomicAdd(&ctl[MWC_GENN], 1);
+                if (slot < GP_GEN) S.gen[slot] = k;
+                S.pool[i] = ~0ull;
+            }
+        }
+        __syncthreads();
+        M = ctl[MWC_GENN];
+        if (tid == 0) ctl[MWC_TMIN] = (int)0xFFFFFFFFu;
+        if (M > GP_GEN) return false;
+        // pop order of the generation: rank = number of smaller keys (keys are unique)
+        {
+            unsigned long long my[2];
+            int c[2] = {0, 0};
+#pragma unroll
+            for (int k = 0; k < 2; k++) my[k] = tid + k * MW_T < M ? S.gen[tid + k * MW_T] : ~0ull;
+            if (M <= MW_T) {
+                for (int j = 0; j < M; j++) c[0] += S.gen[j] < my[0] ? 1 : 0;
+            } else {
+                for (int j = 0; j < M; j++) { const unsigned long long kj = S.gen[j]; c[0] += kj < my[0] ? 1 : 0; c[1] += kj < my[1] ? 1 : 0; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 2; k++) if (tid + k * MW_T < M) S.gen[c[k]] = my[k];
+        }
+        __syncthreads();
+    }
+    return true;
+}
+
+// the estimates on one wave: claim the next slot of the ready queue, wait for its fill, estimate, release the fills that waited for it
 template <int NS>
 __device__ __attribute__((always_inline)) inline void mw_fill_loop(const TeleaWin &win, const TeleaMarchConsts &mc, const uint16_t *fi, const uint16_t *flist,
                                                                    uint32_t *dep, uint16_t *rq, int *ctl, int nfill, int lane)
@@ -72,17 +331,18 @@ __device__ __attribute__((always_inline)) inline void mw_fill_loop(const TeleaWi
         const int pi = flist[k];
         telea_fill_known_T<NS>(win, mc, pi, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-#pragma unroll
-        for (int c2 = 0; c2 < 2; c2++) {
-            if (!non[c2]) continue;
-            const unsigned c = fi[pi + noff[c2]];
-            if (c > k && c < FI_NOHOLE) {
+        auto release = [&](bool on, int off) {
+            if (!on) return;
+            const unsigned c = fi[pi + off];
+            if (c > k && c < FI_FILLED) {
                 if (atomicSub(&dep[c], 1u) == 1u) {
                     const int slot = atomicAdd(&ctl[MWC_TAIL], 1);
                     ((volatile uint16_t *)rq)[slot] = (uint16_t)c;
                 }
             }
-        }
+        };
+        release(non[0], noff[0]);
+        release(non[1], noff[1]);
     }
 }
 
@@ -106,22 +366,28 @@ __global__ __launch_bounds__(MW_T) void k_telea_window_mw(float *__restrict__ im
     float *img = img_all + (size_t)b * P;
     const uint8_t *bad = bad_all + (size_t)b * P;
 
-    unsigned long long *qo = (unsigned long long *)mw_lds;       // [MW_QCAP] outside pass; phase 3: dependence counters u32 [MW_FILLS]
-    unsigned long long *qa = qo + MW_QCAP;                       // [MW_QCAP] ordering pass; phase 3: ready queue u16 [MW_FILLS]
-    float *t = (float *)(qa + MW_QCAP);                          // [MW_CELLS]
-    float *im = t + MW_CELLS;                                    // [MW_CELLS]
+    unsigned char *regA = mw_lds;                                // [MW_REGION_A]
+    float *t = (float *)(regA + MW_REGION_A);                    // [MW_CELLS]
+    float *im = t + MW_CELLS;                                    // [MW_CELLS]; generation scratch until the image is loaded
     uint16_t *fi = (uint16_t *)(im + MW_CELLS);                  // [MW_CELLS]
     uint16_t *flist = fi + MW_CELLS;                             // [MW_FILLS]
-    uint32_t *hotL = (uint32_t *)(flist + MW_FILLS);             // [2][64]
-    int *ctl = (int *)(hotL + 128);                              // [MWC_N]
+    int *cntv = (int *)(flist + MW_FILLS);                       // [GP_CNT]
+    int *ctl = cntv + GP_CNT;                                    // [MWC_N]
     uint8_t *f = (uint8_t *)(ctl + MWC_N);                       // [MW_CELLS]
+    GenScratch S;
+    S.pool = (unsigned long long *)regA;
+    S.gen = (unsigned long long *)im;
+    S.dep = (uint32_t *)(S.gen + GP_GEN);
+    S.rq = (uint16_t *)(S.dep + GP_GEN);
+    S.bitmap = (uint32_t *)(S.rq + GP_GEN);
+    S.cnt = cntv;
+    S.ctl = ctl;
     const uint32_t mg_ww = (uint32_t)(0x100000000ull / (unsigned)ww) + 1u;       // li / ww == umulhi(li, mg_ww) for li < 2^16
     MSTAMP(0);
 
-    // ---- phase 0: window load (hole / border bits, T = 1e6, image), four cells per thread in flight
+    // ---- window flags (hole / border bits), T = 1e6
     if (tid < MWC_N) ctl[tid] = 0;
     for (int base = 0; base < cells; base += MW_T * 4) {
-        float v[4];
         uint8_t bd[4];
         bool interior[4];
 #pragma unroll
@@ -131,7 +397,6 @@ __global__ __launch_bounds__(MW_T) void k_telea_window_mw(float *__restrict__ im
             const int gi = i0 + r, gj = j0 + cc;
             interior[k] = li < cells && gi >= 1 && gi <= h && gj >= 1 && gj <= w;
             const size_t gp = interior[k] ? (size_t)(gi - 1) * w + (gj - 1) : 0;
-            v[k] = img[gp];
             bd[k] = bad[gp];
         }
 #pragma unroll
@@ -139,7 +404,6 @@ __global__ __launch_bounds__(MW_T) void k_telea_window_mw(float *__restrict__ im
             const int li = base + k * MW_T + tid;
             if (li >= cells) continue;
             const bool hole = interior[k] && bd[k];
-            im[li] = interior[k] ? v[k] : 0.f;
             f[li] = !interior[k] ? W_BORDER : hole ? W_HOLE : (uint8_t)0;
             fi[li] = hole ? FI_INSIDE : FI_NOHOLE;
             t[li] = 1.0e6f;
@@ -195,50 +459,43 @@ __global__ __launch_bounds__(MW_T) void k_telea_window_mw(float *__restrict__ im
     __syncthreads();
     MSTAMP(1);
 
-    // ---- phase 1: the two FMM passes side by side
-    if (wave == 0) {
-        WQ q;
-        q.e = qo; q.hotL = hotL; q.ovf = 0; q.cap = MW_QCAP;
-        wq_init(q);
-        FmmFlagState st{t, f};
-        unsigned long long np = 0, ns = 0;
-        telea_fmm_pass(st, q, f, cells, ww, lane, np, ns);
-        if (q.ovf && lane == 0) ctl[MWC_FAIL] = 1;
-        MSTAMP_W(2);
-#ifdef VISTAF_DEBUG
-        if (lane == 0 && b < 1024) g_mw_dbg[b][8] = (np << 32) | ns;
-#endif
-    } else if (wave == 1) {
-        WQ q;
-        q.e = qa; q.hotL = hotL + 64; q.ovf = 0; q.cap = MW_QCAP;
-        wq_init(q);
-        FmmOrderState st{t, fi, flist, 0, MW_FILLS};
-        unsigned long long np = 0, ns = 0;
-        telea_fmm_pass(st, q, f, cells, ww, lane, np, ns);
-        if (lane == 0) {
-            ctl[MWC_NFILL] = st.n;
-            if (q.ovf || st.n > MW_FILLS) ctl[MWC_FAIL] = 1;
-        }
-        MSTAMP_W(3);
-#ifdef VISTAF_DEBUG
-        if (lane == 0 && b < 1024) g_mw_dbg[b][9] = (np << 32) | ns;
-#endif
-    }
+    // ---- the two FMM passes.  They touch disjoint cells apart from the band pixels both start from (ring cells have no hole neighbour,
+    // hole pixels no ring neighbour; band pixels keep T = 0), so their order does not matter
+    bool ok = gp_pass<false>(S, t, f, fi, flist, cells, wh, ww, mg_ww, tid, lane, wave);
+    MSTAMP(2);
     __syncthreads();
-    MSTAMP(4);
-    if (ctl[MWC_FAIL]) { if (tid == 0) fb[b] = 1; return; }       // nothing has been written back: the single-wave tier marches this frame
+    if (ok) ok = gp_pass<true>(S, t, f, fi, flist, cells, wh, ww, mg_ww, tid, lane, wave);
+    MSTAMP(3);
     const int nfill = ctl[MWC_NFILL];
-
-    // ---- phase 2: negate T where the outside pass ran, the march's states (hole = INSIDE, rest KNOWN), dependence counters
-    uint32_t *dep = (uint32_t *)qo;
-    uint16_t *rq = (uint16_t *)qa;
-    for (int li = tid; li < cells; li += MW_T) {
-        const uint8_t v = f[li];
-        if ((v & W_ST) == W_CHANGE) t[li] = -t[li];
-        f[li] = (uint8_t)((v & (W_SEED | W_HOLE | W_BORDER)) | ((v & W_HOLE) ? W_INSIDE : W_KNOWN));
-    }
-    for (int k = tid; k < nfill; k += MW_T) rq[k] = 0xFFFFu;
+    if (!ok || nfill > MW_FILLS) { if (tid == 0) fb[b] = 1; return; }     // nothing has been written back: the single-wave tier marches this frame
     __syncthreads();
+
+    // ---- image into the window; negate T where the outside pass ran; the march's states (hole = INSIDE, rest KNOWN); fill numbers
+    uint32_t *dep = (uint32_t *)regA;
+    uint16_t *rq = (uint16_t *)(dep + MW_FILLS);
+    for (int base = 0; base < cells; base += MW_T * 4) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int li = base + k * MW_T + tid;
+            const bool interior = li < cells && !(f[li < cells ? li : 0] & W_BORDER);
+            const int r = (int)__umulhi((uint32_t)li, mg_ww), cc = li - r * ww;
+            v[k] = interior ? img[(size_t)(i0 + r - 1) * w + (j0 + cc - 1)] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int li = base + k * MW_T + tid;
+            if (li >= cells) continue;
+            im[li] = v[k];
+            const uint8_t fv = f[li];
+            if ((fv & W_ST) == W_CHANGE) t[li] = -t[li];
+            f[li] = (uint8_t)((fv & (W_SEED | W_HOLE | W_BORDER)) | ((fv & W_HOLE) ? W_INSIDE : W_KNOWN));
+        }
+    }
+    for (int k = tid; k < nfill; k += MW_T) { fi[flist[k]] = (uint16_t)k; rq[k] = 0xFFFFu; }
+    if (tid == 0) { ctl[MWC_HEAD] = 0; ctl[MWC_TAIL] = 0; }
+    __syncthreads();
+    // dependence counters: earlier fills within Chebyshev distance range + 1 (the reach of a fill's reads)
     {
         const int D = range + 1;
         for (int k = tid; k < nfill; k += MW_T) {
@@ -246,16 +503,16 @@ __global__ __launch_bounds__(MW_T) void k_telea_window_mw(float *__restrict__ im
             uint32_t cnt = 0;
             for (int dk = -D; dk <= D; dk++) {
                 const uint16_t *row = fi + pi + dk * ww;
-                for (int dl = -D; dl <= D; dl++) cnt += row[dl] < (unsigned)k ? 1u : 0u;       // FI_NOHOLE / FI_INSIDE never are
+                for (int dl = -D; dl <= D; dl++) cnt += row[dl] < (unsigned)k ? 1u : 0u;       // FI_NOHOLE is not
             }
             dep[k] = cnt;
             if (cnt == 0) { const int slot = atomicAdd(&ctl[MWC_TAIL], 1); rq[slot] = (uint16_t)k; }
         }
     }
     __syncthreads();
-    MSTAMP(5);
+    MSTAMP(4);
 
-    // ---- phase 3: the estimates
+    // ---- the estimates
     {
         TeleaWin win;
         win.t = t; win.im = im; win.f = f; win.ww = ww;
@@ -268,16 +525,16 @@ __global__ __launch_bounds__(MW_T) void k_telea_window_mw(float *__restrict__ im
         }
     }
     __syncthreads();
-    MSTAMP(6);
+    MSTAMP(5);
 
-    // ---- phase 4: write back the hole pixels
+    // ---- write back the hole pixels
     for (int li = tid; li < cells; li += MW_T) {
         if (!(f[li] & W_HOLE)) continue;
         const int r = (int)__umulhi((uint32_t)li, mg_ww), cc = li - r * ww;
         img[(size_t)(i0 + r - 1) * w + (j0 + cc - 1)] = im[li];
     }
     if (tid == 0) fb[b] = 0;
-    MSTAMP(7);
+    MSTAMP(6);
 #ifdef VISTAF_DEBUG
     if (tid == 0 && b < 1024) g_mw_dbg[b][10] = ((unsigned long long)nfill << 32) | (unsigned)cells;
 #endif
@@ -300,15 +557,14 @@ void telea_window_mw_debug_dump(int B)
     int worst = 0;
     double mean = 0;
     for (int b = 0; b < B && b < 1024; b++) {
-        if (hbuf[b][7] - hbuf[b][0] > hbuf[worst][7] - hbuf[worst][0]) worst = b;
-        mean += (double)(hbuf[b][7] - hbuf[b][0]) / B;
+        if (hbuf[b][6] - hbuf[b][0] > hbuf[worst][6] - hbuf[worst][0]) worst = b;
+        mean += (double)(hbuf[b][6] - hbuf[b][0]) / B;
     }
     for (int b : {0, worst}) {
         unsigned long long *x = hbuf[b];
-        printf("[telea mw dbg] frame %d cycles: load+ring %llu | outside pass %llu (%llu pops in %llu steps) | ordering pass %llu (%llu pops in %llu steps) | "
-               "phase 1 %llu | negate+counters %llu | fills %llu | write back %llu | fills %llu cells %llu | mean total over frames %.0f\n",
-               b, x[1] - x[0], x[2] - x[1], x[8] >> 32, x[8] & 0xffffffffull, x[3] - x[1], x[9] >> 32, x[9] & 0xffffffffull, x[4] - x[1], x[5] - x[4],
-               x[6] - x[5], x[7] - x[6], x[10] >> 32, x[10] & 0xffffffffull, mean);
+        printf("[telea mw dbg] frame %d cycles: flags+ring %llu | outside pass %llu | ordering pass %llu | image+negate+counters %llu | fills %llu | "
+               "write back %llu | fills %llu cells %llu | mean total over frames %.0f\n",
+               b, x[1] - x[0], x[2] - x[1], x[3] - x[2], x[4] - x[3], x[5] - x[4], x[6] - x[5], x[10] >> 32, x[10] & 0xffffffffull, mean);
     }
 }
 #endif

@@ -343,14 +343,8 @@ __device__ inline int telea_outside_prefix(const int (&cells)[4], int n, int ww,
     }
     return m;
 }
-// Where an FMM pass keeps its states.  The pass itself (pop the smallest (T, push order), give every INSIDE 4-neighbour its T, push it) is
-// the same for the outside ring and for the hole: only "which cells are still INSIDE" and what a fill records differ.
-//  * FmmFlagState: OpenCV's `out` flags in the window's flag bytes (outside pass: ring = INSIDE, hole and everything else KNOWN).
-//  * FmmOrderState: the march over the hole WITHOUT its estimator.  T, the pop order and the flag history of cv::inpaint's march depend on
-//    the mask only (FastMarching_solve reads f and t, never the image), so this pass fixes T of every hole pixel and the sequence in which
-//    the march fills them; the estimates are then evaluated in any order that respects their data dependences (k_inpaint_mw.hip).
-//    fi[cell]: 0xFFFF = hole pixel not filled yet (INSIDE), 0xFFFE = not a hole pixel, otherwise the fill's number; list[k] = cell of fill k.
-constexpr uint16_t FI_INSIDE = 0xFFFFu, FI_NOHOLE = 0xFFFEu;
+// Where the FMM pass keeps its states: OpenCV's `out` flags in the window's flag bytes (outside pass: ring = INSIDE, hole and everything
+// else KNOWN).  (A policy rather than plain code so that the pass reads the same whichever plane holds the states.)
 struct FmmFlagState {
     float *t;
     uint8_t *f;
@@ -358,20 +352,6 @@ struct FmmFlagState {
     __device__ __attribute__((always_inline)) void popped(int p, bool seed) const { f[p] = (uint8_t)(seed ? (W_SEED | W_CHANGE) : W_CHANGE); }   // ring pixels carry no other bit that matters
     __device__ __attribute__((always_inline)) void filled(int pn, float T, int) const { t[pn] = T; f[pn] = W_BAND; }
     __device__ __attribute__((always_inline)) void advance(int) {}
-};
-struct FmmOrderState {
-    float *t;
-    uint16_t *fi, *list;
-    int n, cap;                 // fills so far (wave-uniform), capacity of list
-    __device__ __attribute__((always_inline)) bool inside(int c) const { return fi[c] == FI_INSIDE; }
-    __device__ __attribute__((always_inline)) void popped(int, bool) const {}        // KNOWN or BAND: the pass only asks "INSIDE?"
-    __device__ __attribute__((always_inline)) void filled(int pn, float T, int ord) const
-    {
-        const int k = n + ord;
-        t[pn] = T; fi[pn] = (uint16_t)(k < cap ? k : cap);        // (beyond the capacity the frame is handed back; any value != INSIDE keeps the pass going)
-        if (k < cap) list[k] = (uint16_t)pn;
-    }
-    __device__ __attribute__((always_inline)) void advance(int cnt) { n += cnt; }
 };
 
 // cellT = the float bits of the candidates' T (all 0 for the seeds, which never wait for a push); commit(k) removes the k entries
@@ -667,7 +647,7 @@ __device__ __attribute__((always_inline)) inline int telea_pop_march(const Telea
     return nfill;
 }
 
-// The estimate of ONE hole pixel pi whose T the ordering pass (FmmOrderState) has already fixed: the fill block of telea_pop_march without
+// The estimate of ONE hole pixel pi whose T the ordering pass (k_inpaint_mw.hip) has already fixed: the fill block of telea_pop_march without
 // the quadrant solve and the push, same operations in the same order (so the value carries the same bits).  The caller guarantees that
 // every fill within Chebyshev distance range + 1 of pi runs in march order (the block reads flags, T and image values that far out):
 // then "flag != INSIDE" in the live flag bytes is exactly the flag history cv::inpaint's march would have seen at this fill.
