@@ -166,8 +166,16 @@ def test_unwrap_with_true_wraps_and_parent_tree(pkg, cal):
     torch.cuda.synchronize()
     rs = O.make_reference_state(ref, *pkg.synth.roi_circle(n), cfg)
     P = n * n
-    uw_all = sensor.intermediate("unwrapped", nb).cpu().numpy()
-    wr_all = sensor.intermediate("wrapped", nb).cpu().numpy()
+    uw_all = sensor.intermediate("unwrapped", nb).cpu().numpy().copy()
+    wr_all = sensor.intermediate("wrapped", nb).cpu().numpy().copy()
+    # these frames are path-independent on the reliable mask: the consistency check (k_unwrap_fast.hip) settled them without the flood ...
+    assert (sensor.intermediate("unwrap_need", nb, torch.int32).cpu().numpy() == 0).all()
+    # ... and the priority flood (check off) gives the same plane bit for bit, plus the spanning tree compared below
+    sensor._test_set("unwrap_fast", 0)
+    out_flood = sensor.predict_batch(frames)
+    torch.cuda.synchronize()
+    assert np.array_equal(sensor.intermediate("unwrapped", nb).cpu().numpy(), uw_all, equal_nan=True)
+    assert np.array_equal(out_flood["height_map_mm"].cpu().numpy(), out["height_map_mm"].cpu().numpy(), equal_nan=True)
     par_all = sensor.intermediate("parent", nb, torch.int32).cpu().numpy()
     saw_wrap = False
     for b in range(nb):
@@ -388,7 +396,7 @@ def test_non_square_odd_sizes(pkg, cal):
 
 
 
-@pytest.mark.parametrize("var,val", [("inpaint_tier", 1), ("inpaint_tier", 0), ("flood_tier", 1), ("flood_tier", 0), ("chamfer_twopass", 1)])
+@pytest.mark.parametrize("var,val", [("inpaint_tier", 1), ("inpaint_tier", 0), ("flood_tier", 1), ("flood_tier", 0), ("chamfer_twopass", 1), ("unwrap_fast", 0)])
 def test_alternative_kernel_tiers_agree(pkg, cal, var, val):
     """The fallback / opt-in kernels (whole-frame and cluster-parallel Telea, one-pop and scan floods, two-pass chamfer) stay
     parity-green: same frames through the default path and through the alternative, compared with each other and with the oracle."""
@@ -396,6 +404,8 @@ def test_alternative_kernel_tiers_agree(pkg, cal, var, val):
     cfg = pkg.FtpConfig.scaled(n)
     ref, sensor = _sensor(pkg, cal, n, cfg, nb, config=3)
     frames = pkg.synth.deformed_batch(n, 40, nb, config=3)
+    if var == "flood_tier":
+        sensor._test_set("unwrap_fast", 0)                                  # the flood tiers are compared tree by tree: every frame through the flood
     base = sensor.predict_batch(frames)
     torch.cuda.synchronize()
     hm0 = base["height_map_mm"].cpu().numpy().copy()
@@ -408,8 +418,11 @@ def test_alternative_kernel_tiers_agree(pkg, cal, var, val):
     par1 = sensor.intermediate("parent", nb, torch.int32).cpu().numpy().copy()
     st = alt["status"].cpu().numpy()
     assert (st == 0).all()
-    if var != "inpaint_tier":
-        assert np.array_equal(par0, par1)                                   # the growth tree is an integer result: identical
+    if var == "unwrap_fast":
+        assert np.array_equal(hm0, hm1, equal_nan=True)                     # consistency check + parallel integration against the priority flood
+    elif var != "inpaint_tier":
+        if var == "flood_tier":
+            assert np.array_equal(par0, par1)                               # the growth tree is an integer result: identical
         assert np.array_equal(hm0, hm1, equal_nan=True)
     else:
         # every Telea tier (frame window, whole frame, cluster by cluster in LDS windows / on the global planes) pops in the queue's order and
@@ -677,3 +690,82 @@ def test_module_level_predict_is_the_drop_in(pkg, cal):
     assert float(np.nanmax(np.abs(res2["height_map_mm_crop"] - o2["height_map_mm_crop"]))) <= RTOL * float(np.nanmax(np.abs(o2["height_map_mm_crop"])))
     with pytest.raises(RuntimeError):
         pkg.predict(np.zeros((n + 1, n), np.uint8))                                            # size mismatch (shape_ftp.py:1477)
+
+
+def _vortex_frame(pkg, n, seed, x0, y0, charge=1):
+    """A deformed frame whose fringes fork at (x0, y0): phi gains charge * atan2(y - y0, x - x0), a phase residue inside the ROI.  The wrapped
+    phase difference then sums to 2 pi * charge around the fork, so the unwrapped plane depends on the spanning tree the flood grows."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:n, 0:n].astype(np.float64)
+    phi = -0.6 * np.exp(-((xx - 0.4 * n) ** 2 + (yy - 0.55 * n) ** 2) / (2.0 * (0.15 * n) ** 2)) + charge * np.arctan2(yy - y0, xx - x0)
+    return pkg.synth._base(n, phi, rng)
+
+
+def test_unwrap_consistency_check_falls_back_on_a_residue(pkg, cal):
+    """k_unwrap_fast.hip settles a frame only when every 8-adjacent pair of the seed's component satisfies k[b] - k[a] = c(a -> b); then
+    any spanning tree gives the same plane.  Frames 0 and 2 carry a fringe fork (a phase residue) inside the reliable mask: the check must
+    refuse them (need = 1) and the priority flood must produce the reference's tree-dependent plane -- same wrap counts and same parents
+    as the oracle's heap order; frame 1 is an ordinary frame and is settled by the check (need = 0).  The whole batch is then repeated with
+    the check off: identical planes."""
+    n, nb = 224, 3
+    cfg = pkg.FtpConfig.scaled(n)
+    ref, sensor = _sensor(pkg, cal, n, cfg, nb, config=3)
+    frames = np.stack([_vortex_frame(pkg, n, 77001, 0.62 * n, 0.40 * n), pkg.synth.deformed_frame(n, 3, config=3), _vortex_frame(pkg, n, 77002, 0.35 * n, 0.60 * n, -1)])
+    out = sensor.predict_batch(frames)
+    torch.cuda.synchronize()
+    need = sensor.intermediate("unwrap_need", nb, torch.int32).cpu().numpy()
+    assert need.tolist() == [1, 0, 1]
+    P = n * n
+    uw_all = sensor.intermediate("unwrapped", nb).cpu().numpy().copy()
+    wr_all = sensor.intermediate("wrapped", nb).cpu().numpy().copy()
+    par_all = sensor.intermediate("parent", nb, torch.int32).cpu().numpy().copy()
+    qg_all = sensor.intermediate("quality", nb).cpu().numpy().copy()
+    hm = out["height_map_mm"].cpu().numpy().copy()
+    rs = O.make_reference_state(ref, *pkg.synth.roi_circle(n), cfg)
+    from oracle import cvlite
+    for b in range(nb):
+        o = O.process_frame(frames[b], rs, cfg, *cal, keep_intermediates=True)
+        it = o["inter"]
+        uo = it["unwrapped"]
+        uw = uw_all[b * P:(b + 1) * P].reshape(n, n)
+        wr = wr_all[b * P:(b + 1) * P].reshape(n, n)
+        assert np.array_equal(np.isnan(uw), np.isnan(uo)), b
+        m = ~np.isnan(uo)
+        k_gpu = np.rint((uw[m] - wr[m]) / (2 * np.pi))
+        k_ora = np.rint((uo[m] - it["wrapped"][m]) / (2 * np.pi))
+        assert np.array_equal(k_gpu, k_ora), b
+        if need[b]:
+            assert np.any(k_ora != 0), b                       # the residue forces a 2 pi cut somewhere in the mask
+            assert np.array_equal(qg_all[b * P:(b + 1) * P].reshape(n, n)[rs["roi"]], it["quality"][rs["roi"]])
+            _, par_o, _ = cvlite.unwrap_quality_guided(it["wrapped"], o["reliable"], it["quality"], want_tree=True)
+            assert np.array_equal(par_all[b * P:(b + 1) * P].reshape(n, n), par_o), b
+    sensor._test_set("unwrap_fast", 0)
+    out2 = sensor.predict_batch(frames)
+    torch.cuda.synchronize()
+    assert np.array_equal(sensor.intermediate("unwrapped", nb).cpu().numpy(), uw_all, equal_nan=True)
+    assert np.array_equal(out2["height_map_mm"].cpu().numpy(), hm, equal_nan=True)
+
+
+def test_unwrap_consistency_check_against_flood_on_many_frames(pkg, cal):
+    """96 frames (three amplitude scales, genuine 2 pi wraps among them) through the consistency check + parallel integration and through the
+    priority flood: the unwrapped planes must be the same bits, frame by frame, NaN layout included."""
+    n, nb = 224, 96
+    cfg = pkg.FtpConfig.scaled(n)
+    ref, sensor = _sensor(pkg, cal, n, cfg, nb, config=3)
+    frames = np.concatenate([pkg.synth.deformed_batch(n, 4000, 32, config=3), pkg.synth.deformed_batch(n, 4100, 32, config=3, amp_scale=9.0),
+                             pkg.synth.deformed_batch(n, 4200, 32, config=3, amp_scale=0.4)])
+    out = sensor.predict_batch(frames)
+    torch.cuda.synchronize()
+    need = sensor.intermediate("unwrap_need", nb, torch.int32).cpu().numpy()
+    uw = sensor.intermediate("unwrapped", nb).cpu().numpy().copy()
+    wr = sensor.intermediate("wrapped", nb).cpu().numpy().copy()
+    hm = out["height_map_mm"].cpu().numpy().copy()
+    assert (need == 0).sum() >= nb // 2, need.tolist()         # the check settles these frames (all of them, in practice)
+    fin = np.isfinite(uw)
+    assert np.any(np.rint((uw[fin] - wr[fin]) / (2 * np.pi)) != 0)   # the batch does contain wrapped pixels
+    sensor._test_set("unwrap_fast", 0)
+    out2 = sensor.predict_batch(frames)
+    torch.cuda.synchronize()
+    assert np.array_equal(sensor.intermediate("unwrapped", nb).cpu().numpy(), uw, equal_nan=True)
+    assert np.array_equal(out2["height_map_mm"].cpu().numpy(), hm, equal_nan=True)
+    assert (out["status"].cpu().numpy() == out2["status"].cpu().numpy()).all()

@@ -87,6 +87,7 @@ struct vistaf_ftp_handle {
     unsigned int *peak_bits;
     uint16_t *morph_pre;
     void *inpaint_scratch, *inpaint_cl_scratch, *inpaint_win_scratch, *unwrap_scratch;
+    int32_t *unwrap_need;       // [max_batch] 1: the frame went through the priority flood, 0: the consistency check settled it
     // small per-frame arrays
     float *thr_hi, *thr_g, *mu, *amp_thr, *thr3, *thr_used, *bg_med, *core_thr, *core_med, *coef;
     int *cnt_a, *cnt_valid, *rel_count, *contact_count, *bg_count, *bad_count, *flipped;
@@ -384,6 +385,8 @@ int vistaf_ftp_create(const vistaf_ftp_config *cfg, int h, int w, int cx, int cy
         TRY(dalloc(hd, (uint8_t **)&p, inpaint_cl_scratch_bytes_per_frame(h, w) * max_batch + 2048)); hd->inpaint_cl_scratch = p;
         TRY(dalloc(hd, (uint8_t **)&p, inpaint_win_scratch_bytes(max_batch))); hd->inpaint_win_scratch = p;
         TRY(dalloc(hd, (uint8_t **)&p, unwrap_scratch_bytes_per_frame(h, w) * max_batch + 1024)); hd->unwrap_scratch = p;
+        TRY(dalloc(hd, &hd->unwrap_need, (size_t)max_batch, "unwrap_need", sizeof(int32_t)));
+        HIPCHK(hipMemset(hd->unwrap_need, 0xff, (size_t)max_batch * sizeof(int32_t)));        // -1: never written (the check is off or does not cover this frame size)
     }
     int pmax = 2 * bwp + 1;
     hd->pmax = pmax;
@@ -567,7 +570,7 @@ static int post_demod(vistaf_ftp_handle *hd, int B, float *d_height_mm, uint8_t 
     // ---- unwrap (shape_ftp.py:1702)
     if (timed) hipEventRecord(hd->ev[ST_UNWRAP_RANK], st);
     launch_unwrap(hd->wrapped, qual, hd->reliable, hd->unwrapped, hd->parent, hd->unwrap_scratch, hd->status, B, h, w, st,
-                  timed ? hd->ev[ST_UNWRAP_TREE] : nullptr, timed ? hd->ev[ST_UNWRAP] : nullptr, hd->tiers.flood);
+                  timed ? hd->ev[ST_UNWRAP_TREE] : nullptr, timed ? hd->ev[ST_UNWRAP] : nullptr, hd->tiers.flood, hd->tiers.unwrap_fast ? hd->unwrap_need : nullptr);
 
     // ---- plane removal + two-pass detrend (shape_ftp.py:1706, :1716-1751)
     if (timed) hipEventRecord(hd->ev[ST_DETREND], st);
@@ -806,6 +809,7 @@ int vistaf_ftp_test_set(vistaf_ftp_handle *hd, const char *name, int value)
     else if (n == "telea_two_tier") hd->tiers.telea_two_tier = value != 0;
     else if (n == "fit_capped") hd->tiers.fit_capped = value != 0;
     else if (n == "telea_mw") hd->tiers.telea_mw = value != 0;
+    else if (n == "unwrap_fast") hd->tiers.unwrap_fast = value != 0;
     else if (n == "keep_planes") hd->keep_planes = value != 0;
     else return fail(VISTAF_E_INVALID, "unknown test hook or value: " + n);
     return 0;

@@ -41,25 +41,29 @@ constexpr int GP_CNT = 256;         // chunk counts / bitmap prefix
 // fill-number plane: hole pixel not filled yet / not a hole pixel / filled (number pending) / queued in the current generation with rank r
 constexpr uint16_t FI_INSIDE = 0x3FFFu, FI_NOHOLE = 0x3FFEu, FI_FILLED = 0x3FFDu, FI_PEND = 0x8000u;
 enum { MWC_FAIL = 0, MWC_NFILL, MWC_HEAD, MWC_TAIL, MWC_POOLN, MWC_GENN, MWC_TMIN, MWC_N = 16 };
-constexpr size_t MW_REGION_A = (size_t)GP_POOL * 8;          // FMM: pool; fills: dependence counters u32 + ready queue u16
+constexpr size_t MW_REGION_A = (size_t)GP_POOL * 8;          // FMM: pool; fills: dependence counters u32 + ready queue u32
 constexpr size_t MW_LDS = MW_REGION_A + (size_t)MW_CELLS * 11 + (size_t)MW_FILLS * 2 + GP_CNT * 4 + MWC_N * 4;
 static_assert(MW_LDS <= 160 * 1024, "one CU's LDS");
-static_assert((size_t)MW_FILLS * 6 <= MW_REGION_A, "dependence counters and ready queue of the fills");
-static_assert((size_t)GP_GEN * (8 + 4 + 2) + GP_GEN * 4 / 8 <= (size_t)MW_CELLS * 4, "generation scratch lives in the image plane until the image is loaded");
+static_assert((size_t)MW_FILLS * 8 <= MW_REGION_A, "dependence counters and ready queue of the fills");
+static_assert((size_t)GP_GEN * (8 + 4) + GP_GEN * 4 / 8 <= (size_t)MW_CELLS * 4, "generation scratch lives in the image plane until the image is loaded");
 static_assert(MW_FILLS < FI_FILLED && GP_GEN <= 0x800 && MW_CELLS <= 0x4000 && MW_CELLS / 64 <= GP_CNT && GP_GEN * 4 / 32 <= GP_CNT, "field widths");
 
 #ifdef VISTAF_DEBUG
 __device__ unsigned long long g_mw_dbg[1024][16];
 #define MSTAMP(i) do { if (threadIdx.x == 0 && b < 1024) g_mw_dbg[b][i] = __builtin_amdgcn_s_memtime(); } while (0)
+// cycle sums over the generations of both passes: [11] marks + counters, [12] pops, [13] numbering, [14] next generation (min, select, sort), [15] generations
+#define GACC(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); g_mw_dbg[blockIdx.x][i] += t_ - gstamp_; gstamp_ = t_; } } while (0)
+#define GSTART() unsigned long long gstamp_ = __builtin_amdgcn_s_memtime()
 #else
 #define MSTAMP(i) do { } while (0)
+#define GACC(i) do { } while (0)
+#define GSTART() do { } while (0)
 #endif
 
 struct GenScratch {
     unsigned long long *pool;       // [GP_POOL] (T bits | generation | parent's rank | neighbour | cell), blank = ~0
     unsigned long long *gen;        // [GP_GEN] the current generation in pop order
     uint32_t *dep;                  // [GP_GEN] earlier entries of the generation within Manhattan distance 3 that have not popped yet
-    uint16_t *rq;                   // [GP_GEN] ready queue
     uint32_t *bitmap;               // [GP_GEN * 4 / 32] fills of the generation by (rank, neighbour)
     int *cnt;                       // [GP_CNT]
     int *ctl;
@@ -76,8 +80,8 @@ __device__ inline int wave_excl_scan(int v, int lane, int &total)
     return s - v;
 }
 
-// the pops of one generation on one wave: claim the next slot of the ready queue, wait for its entry, pop it, release the entries that
-// waited for it.  ORDER: the march's ordering pass (states in the fill-number plane), else the outside pass (states in the flag bytes)
+// the pops of one generation on one wave: claim the next entry in pop order, wait until the earlier entries in reach have popped, pop it,
+// release the later entries in reach.  ORDER: the march's ordering pass (states in the fill-number plane), else the outside pass (states in the flag bytes)
 template <bool ORDER>
 __device__ __attribute__((always_inline)) inline void gp_pop_loop(const GenScratch &S, float *t, uint8_t *f, uint16_t *fi, int M, int g, int wh, int ww,
                                                                   uint32_t mg_ww, int lane)
@@ -104,28 +108,33 @@ __device__ __attribute__((always_inline)) inline void gp_pop_loop(const GenScrat
     }
     const bool non = lane < 24;
     const int noff = ndy * ww + ndx;
-    auto inside = [&](int c) -> bool { return ORDER ? fi[c] == FI_INSIDE : (f[c] & W_ST) == W_INSIDE; };
     int *ctl = S.ctl;
     for (;;) {
-        int s = 0;
-        if (lane == 0) s = atomicAdd(&ctl[MWC_HEAD], 1);
-        s = __builtin_amdgcn_readfirstlane(s);
-        if (s >= M) break;                       // every entry is queued exactly once: slots [0, M) all get one
-        unsigned r;
-        while ((r = ((volatile uint16_t *)S.rq)[s]) == 0xFFFFu) __builtin_amdgcn_s_sleep(1);
-        r = (unsigned)__builtin_amdgcn_readfirstlane((int)r);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // entries are claimed in pop order: the first entry that has not popped yet is always held by a wave and has no open dependence,
+        // so the loop makes progress whatever the other waves wait for
+        int ri = 0;
+        if (lane == 0) ri = atomicAdd(&ctl[MWC_HEAD], 1);
+        ri = __builtin_amdgcn_readfirstlane(ri);
+        if (ri >= M) break;
+        const unsigned r = (unsigned)ri;
         const int p = (int)((uint32_t)S.gen[r] & 0x3FFFu);
-        const int pn = p + oc.dn;
-        const bool ok = lane < 16 && inside(pn);
+        const int pn = p + oc.dn, p1 = pn + oc.d1, p2 = pn + oc.d2;
+        const int py = (int)__umulhi((uint32_t)p, mg_ww), px = p - py * ww;
+        const bool nin = non && py + ndy >= 0 && py + ndy < wh && px + ndx >= 0 && px + ndx < ww;
+        const int pq = nin ? p + noff : p;
+        while (__hip_atomic_load(&S.dep[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) __builtin_amdgcn_s_sleep(1);
+        // every read of the pop in one round: the neighbour's state, the two arguments of its quadrant (lanes beyond the 16 read, unused,
+        // cells next to p; an address outside the window's planes returns junk nobody looks at), the rank marks around p (entries that
+        // wait for this pop keep their mark until they pop themselves)
+        float a11 = t[p1], a22 = t[p2];
+        bool in0, in1, in2;
+        if (ORDER) { const uint16_t s0 = fi[pn], s1 = fi[p1], s2 = fi[p2]; in0 = s0 == FI_INSIDE; in1 = s1 == FI_INSIDE; in2 = s2 == FI_INSIDE; }
+        else { const uint8_t s0 = f[pn], s1 = f[p1], s2 = f[p2]; in0 = (s0 & W_ST) == W_INSIDE; in1 = (s1 & W_ST) == W_INSIDE; in2 = (s2 & W_ST) == W_INSIDE; }
+        const unsigned v = fi[pq];
+        const bool ok = lane < 16 && in0;
         const unsigned long long okb = __ballot(ok);
-        float dist = 0.f;
-        if (okb) {
-            if (ok) {
-                const int p1 = pn + oc.d1, p2 = pn + oc.d2;
-                const float a11 = t[p1], a22 = t[p2];
-                dist = wn_solve(a11, a22, !inside(p1), !inside(p2));
-            }
+        float dist = wn_solve(a11, a22, !in1, !in2);
+        {
             float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dist), 0xB1, 0xf, 0xf, false)); dist = o < dist ? o : dist;
             o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dist), 0x4E, 0xf, 0xf, false)); dist = o < dist ? o : dist;
         }
@@ -134,6 +143,20 @@ __device__ __attribute__((always_inline)) inline void gp_pop_loop(const GenScrat
             else { f[p] = (uint8_t)(g == 0 ? (W_SEED | W_CHANGE) : W_CHANGE); fi[p] = FI_NOHOLE; }
         }
         const unsigned long long pb = okb & 0x1111ull;
+        const bool lead = (pb >> lane) & 1ull;
+        if (lead) {
+            t[pn] = dist;
+            if (ORDER) fi[pn] = FI_FILLED; else f[pn] = W_BAND;
+        }
+        // release the later entries in reach.  The stores above and the decrements below are LDS operations of one wave: the LDS unit
+        // executes them in issue order, so a wave that sees its counter at 0 sees the stores (no s_waitcnt between them: the compiler only
+        // has to keep the order)
+        asm volatile("" ::: "memory");
+        {
+            const unsigned rv = v & 0x7FFFu;
+            if (nin && (v & FI_PEND) && rv > r) __hip_atomic_fetch_sub(&S.dep[rv], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        // the pushes (off the other waves' critical path)
         if (pb) {
             const int cnt = __popcll(pb);
             int base = 0;
@@ -141,26 +164,9 @@ __device__ __attribute__((always_inline)) inline void gp_pop_loop(const GenScrat
             base = __builtin_amdgcn_readfirstlane(base);
             const bool fits = base + cnt <= GP_POOL;
             if (!fits && lane == 0) ctl[MWC_FAIL] = 1;
-            if ((pb >> lane) & 1ull) {
-                t[pn] = dist;
-                if (ORDER) fi[pn] = FI_FILLED; else f[pn] = W_BAND;
+            if (lead) {
                 if (fits) S.pool[base + __popcll(pb & ((1ull << lane) - 1ull))] = gp_key(dist, g, (int)r, nbi, pn);
                 if (ORDER) atomicOr(&S.bitmap[(r * 4 + nbi) >> 5], 1u << ((r * 4 + nbi) & 31));
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (non) {
-            const int py = (int)__umulhi((uint32_t)p, mg_ww), px = p - py * ww;
-            const int y = py + ndy, x = px + ndx;
-            if (y >= 0 && y < wh && x >= 0 && x < ww) {
-                const unsigned v = fi[p + noff];
-                const unsigned rv = v & 0x7FFFu;
-                if ((v & FI_PEND) && rv > r) {
-                    if (atomicSub(&S.dep[rv], 1u) == 1u) {
-                        const int slot = atomicAdd(&ctl[MWC_TAIL], 1);
-                        ((volatile uint16_t *)S.rq)[slot] = (uint16_t)rv;
-                    }
-                }
             }
         }
     }
@@ -202,12 +208,12 @@ __device__ __attribute__((always_inline)) inline bool gp_pass(const GenScratch &
     }
     __syncthreads();
 
+    GSTART();
     for (int g = 0;; g++) {
-        // rank marks, empty ready queue
+        // rank marks
         for (int r = tid; r < M; r += MW_T) {
             const int cell = (int)((uint32_t)S.gen[r] & 0x3FFFu);
             fi[cell] = (uint16_t)(FI_PEND | r);
-            S.rq[r] = 0xFFFFu;
         }
         if (ORDER) for (int i = tid; i < GP_GEN * 4 / 32; i += MW_T) S.bitmap[i] = 0;
         if (tid == 0) { ctl[MWC_HEAD] = 0; ctl[MWC_TAIL] = 0; ctl[MWC_GENN] = 0; }
@@ -231,11 +237,12 @@ __device__ __attribute__((always_inline)) inline bool gp_pass(const GenScratch &
                 }
             }
             S.dep[r] = c;
-            if (c == 0) { const int slot = atomicAdd(&ctl[MWC_TAIL], 1); S.rq[slot] = (uint16_t)r; }
         }
         __syncthreads();
+        GACC(11);
         gp_pop_loop<ORDER>(S, t, f, fi, M, g, wh, ww, mg_ww, lane);
         __syncthreads();
+        GACC(12);
         if (ctl[MWC_FAIL]) return false;
         const int pool_n = ctl[MWC_POOLN];
         if (ORDER) {
@@ -260,6 +267,7 @@ __device__ __attribute__((always_inline)) inline bool gp_pass(const GenScratch &
             __syncthreads();
             if (tid == 0) ctl[MWC_NFILL] = nf0 + (pool_n - pool_n0);
         }
+        GACC(13);
         // the next generation: everything below T_head + 0.70
         {
             uint32_t mn = 0xFFFFFFFFu;
@@ -300,6 +308,10 @@ __device__ __attribute__((always_inline)) inline bool gp_pass(const GenScratch &
             for (int k = 0; k < 2; k++) if (tid + k * MW_T < M) S.gen[c[k]] = my[k];
         }
         __syncthreads();
+        GACC(14);
+#ifdef VISTAF_DEBUG
+        if (threadIdx.x == 0 && blockIdx.x < 1024) g_mw_dbg[blockIdx.x][15]++;
+#endif
     }
     return true;
 }
@@ -307,7 +319,7 @@ __device__ __attribute__((always_inline)) inline bool gp_pass(const GenScratch &
 // the estimates on one wave: claim the next slot of the ready queue, wait for its fill, estimate, release the fills that waited for it
 template <int NS>
 __device__ __attribute__((always_inline)) inline void mw_fill_loop(const TeleaWin &win, const TeleaMarchConsts &mc, const uint16_t *fi, const uint16_t *flist,
-                                                                   uint32_t *dep, uint16_t *rq, int *ctl, int nfill, int lane)
+                                                                   uint32_t *dep, uint32_t *rq, int *ctl, int nfill, int lane)
 {
     const int D = mc.range + 1, side = 2 * D + 1, nn = side * side;         // nn <= 121 for range <= 4: two cells per lane
     int noff[2];
@@ -325,7 +337,7 @@ __device__ __attribute__((always_inline)) inline void mw_fill_loop(const TeleaWi
         s = __builtin_amdgcn_readfirstlane(s);
         if (s >= nfill) break;                   // every fill is queued exactly once: slots [0, nfill) all get an entry
         unsigned k;
-        while ((k = ((volatile uint16_t *)rq)[s]) == 0xFFFFu) __builtin_amdgcn_s_sleep(1);
+        while ((k = __hip_atomic_load(&rq[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0xFFFFFFFFu) __builtin_amdgcn_s_sleep(1);
         k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const int pi = flist[k];
@@ -337,7 +349,7 @@ __device__ __attribute__((always_inline)) inline void mw_fill_loop(const TeleaWi
             if (c > k && c < FI_FILLED) {
                 if (atomicSub(&dep[c], 1u) == 1u) {
                     const int slot = atomicAdd(&ctl[MWC_TAIL], 1);
-                    ((volatile uint16_t *)rq)[slot] = (uint16_t)c;
+                    __hip_atomic_store(&rq[slot], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
         };
@@ -378,12 +390,14 @@ __global__ __launch_bounds__(MW_T) void k_telea_window_mw(float *__restrict__ im
     S.pool = (unsigned long long *)regA;
     S.gen = (unsigned long long *)im;
     S.dep = (uint32_t *)(S.gen + GP_GEN);
-    S.rq = (uint16_t *)(S.dep + GP_GEN);
-    S.bitmap = (uint32_t *)(S.rq + GP_GEN);
+    S.bitmap = S.dep + GP_GEN;
     S.cnt = cntv;
     S.ctl = ctl;
     const uint32_t mg_ww = (uint32_t)(0x100000000ull / (unsigned)ww) + 1u;       // li / ww == umulhi(li, mg_ww) for li < 2^16
     MSTAMP(0);
+#ifdef VISTAF_DEBUG
+    if (tid == 0 && b < 1024) for (int i = 11; i < 16; i++) g_mw_dbg[b][i] = 0;
+#endif
 
     // ---- window flags (hole / border bits), T = 1e6
     if (tid < MWC_N) ctl[tid] = 0;
@@ -472,7 +486,7 @@ __global__ __launch_bounds__(MW_T) void k_telea_window_mw(float *__restrict__ im
 
     // ---- image into the window; negate T where the outside pass ran; the march's states (hole = INSIDE, rest KNOWN); fill numbers
     uint32_t *dep = (uint32_t *)regA;
-    uint16_t *rq = (uint16_t *)(dep + MW_FILLS);
+    uint32_t *rq = dep + MW_FILLS;
     for (int base = 0; base < cells; base += MW_T * 4) {
         float v[4];
 #pragma unroll
@@ -492,7 +506,7 @@ __global__ __launch_bounds__(MW_T) void k_telea_window_mw(float *__restrict__ im
             f[li] = (uint8_t)((fv & (W_SEED | W_HOLE | W_BORDER)) | ((fv & W_HOLE) ? W_INSIDE : W_KNOWN));
         }
     }
-    for (int k = tid; k < nfill; k += MW_T) { fi[flist[k]] = (uint16_t)k; rq[k] = 0xFFFFu; }
+    for (int k = tid; k < nfill; k += MW_T) { fi[flist[k]] = (uint16_t)k; rq[k] = 0xFFFFFFFFu; }
     if (tid == 0) { ctl[MWC_HEAD] = 0; ctl[MWC_TAIL] = 0; }
     __syncthreads();
     // dependence counters: earlier fills within Chebyshev distance range + 1 (the reach of a fill's reads)
@@ -506,7 +520,7 @@ __global__ __launch_bounds__(MW_T) void k_telea_window_mw(float *__restrict__ im
                 for (int dl = -D; dl <= D; dl++) cnt += row[dl] < (unsigned)k ? 1u : 0u;       // FI_NOHOLE is not
             }
             dep[k] = cnt;
-            if (cnt == 0) { const int slot = atomicAdd(&ctl[MWC_TAIL], 1); rq[slot] = (uint16_t)k; }
+            if (cnt == 0) { const int slot = atomicAdd(&ctl[MWC_TAIL], 1); rq[slot] = (uint32_t)k; }
         }
     }
     __syncthreads();
@@ -563,8 +577,10 @@ void telea_window_mw_debug_dump(int B)
     for (int b : {0, worst}) {
         unsigned long long *x = hbuf[b];
         printf("[telea mw dbg] frame %d cycles: flags+ring %llu | outside pass %llu | ordering pass %llu | image+negate+counters %llu | fills %llu | "
-               "write back %llu | fills %llu cells %llu | mean total over frames %.0f\n",
-               b, x[1] - x[0], x[2] - x[1], x[3] - x[2], x[4] - x[3], x[5] - x[4], x[6] - x[5], x[10] >> 32, x[10] & 0xffffffffull, mean);
+               "write back %llu | fills %llu cells %llu | mean total over frames %.0f || both passes, %llu generation changes: marks+counters %llu | pops %llu | "
+               "numbering %llu | min+select+sort %llu\n",
+               b, x[1] - x[0], x[2] - x[1], x[3] - x[2], x[4] - x[3], x[5] - x[4], x[6] - x[5], x[10] >> 32, x[10] & 0xffffffffull, mean, x[15], x[11], x[12], x[13],
+               x[14]);
     }
 }
 #endif

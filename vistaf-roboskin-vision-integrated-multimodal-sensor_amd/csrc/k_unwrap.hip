@@ -25,8 +25,9 @@ __device__ inline uint8_t ld_st(const uint8_t *st, int i, bool lds)
 template <bool LS>
 __global__ __launch_bounds__(64) void k_unwrap_flood(const float *__restrict__ quality_all, const uint8_t *__restrict__ mask_all,
                                                      int32_t *__restrict__ parent_all, uint8_t *gst, uint32_t *gfq, uint32_t *gfi,
-                                                     int cap, int32_t *status, int h, int w, const int32_t *__restrict__ only)
+                                                     int cap, int32_t *status, int h, int w, const int32_t *__restrict__ only, const int32_t *__restrict__ need_frame)
 {
+    if (need_frame && !need_frame[blockIdx.x]) return;        // the consistency check settled this frame (k_unwrap_fast.hip)
     extern __shared__ unsigned char lds_raw[];
     const int lane = threadIdx.x;
     const size_t b = blockIdx.x;
@@ -131,8 +132,9 @@ __device__ inline void st_u64c(unsigned long long *p, unsigned long long v) { __
 
 __global__ __launch_bounds__(1024) void k_unwrap_tree(const float *__restrict__ wrapped_all, int32_t *parent_all,
                                                       const int32_t *__restrict__ ppar_in, size_t gstride, unsigned long long *words_all,
-                                                      float *__restrict__ unwrapped_all, int h, int w, const int32_t *__restrict__ plain_parents)
+                                                      float *__restrict__ unwrapped_all, int h, int w, const int32_t *__restrict__ plain_parents, const int32_t *__restrict__ need_frame)
 {
+    if (need_frame && !need_frame[blockIdx.x]) return;        // the consistency check settled this frame (k_unwrap_fast.hip)
     __shared__ int s_changed;
     const size_t b = blockIdx.x;
     // plain_parents[b] != 0: this frame's parents were written to parent_all directly (generic flood), not to the padded plane
@@ -213,10 +215,12 @@ size_t unwrap_scratch_bytes_per_frame(int h, int w)
 bool unwrap_ranked_supported(int h, int w);
 bool launch_unwrap_ranked(const float *quality, const uint8_t *mask, uint32_t *g0, uint32_t *g1, uint32_t *g2, uint32_t *g3,
                           int32_t *ppar, size_t gstride, uint16_t *rank16, int32_t *seed, int32_t *status, int B, int h, int w,
-                          hipStream_t st, hipEvent_t ev_flood, int flood_tier);
+                          hipStream_t st, hipEvent_t ev_flood, int flood_tier, const int32_t *need);
 void launch_unwrap_replay(const float *wrapped, const uint32_t *order, size_t ostride, const int32_t *ppar, size_t gstride, int32_t *tree,
-                          float *unwrapped, int B, int h, int w, hipStream_t st);
+                          float *unwrapped, int B, int h, int w, hipStream_t st, const int32_t *need);
 bool unwrap_big_supported(int h, int w);
+bool unwrap_fast_supported(int h, int w);
+void launch_unwrap_fast(const float *wrapped, const float *quality, const uint8_t *mask, float *unwrapped, int32_t *need, int B, int h, int w, hipStream_t st);
 void launch_unwrap_rank32(const float *quality, const uint8_t *mask, uint32_t *gA, uint32_t *gB, size_t gstride, uint32_t *rank32, int32_t *seed,
                           int32_t *n_out, int B, int h, int w, hipStream_t st);
 void launch_unwrap_flood_big(uint32_t *code, const int32_t *seed, const int32_t *n, const uint32_t *inv, size_t inv_stride, int32_t *ppar,
@@ -230,7 +234,7 @@ static int unwrap_lds_cap(int P)
 }
 
 void launch_unwrap(const float *wrapped, const float *quality, const uint8_t *mask, float *unwrapped, int32_t *parent,
-                   void *scratch, int32_t *status, int B, int h, int w, hipStream_t st, hipEvent_t ev_mid, hipEvent_t ev_flood, int flood_tier)
+                   void *scratch, int32_t *status, int B, int h, int w, hipStream_t st, hipEvent_t ev_mid, hipEvent_t ev_flood, int flood_tier, int32_t *need_buf)
 {
     int P = h * w;
     size_t n = (size_t)B * P;
@@ -242,16 +246,24 @@ void launch_unwrap(const float *wrapped, const float *quality, const uint8_t *ma
     uint32_t *g1 = g0 + gn, *g2 = g1 + gn, *g3 = g2 + gn, *g4 = g3 + gn;
     int cap = unwrap_lds_cap(P);
     const int32_t *ppar = nullptr;
+    // First the consistency check (k_unwrap_fast.hip): frames whose wrapped field is path-independent on the seed's component get their
+    // plane from a parallel integration, and every kernel of the priority flood below skips them (need[b] = 0).  The parent plane of
+    // such a frame is not produced (it is a by-product of the flood; the parity tests that compare trees switch the check off).
+    const int32_t *need = nullptr;
+    if (need_buf && unwrap_fast_supported(h, w)) {
+        launch_unwrap_fast(wrapped, quality, mask, unwrapped, need_buf, B, h, w, st);
+        need = need_buf;
+    }
     if (unwrap_ranked_supported(h, w)) {
         uint8_t *after = (uint8_t *)(g4 + gn);
         after = (uint8_t *)(((uintptr_t)after + 255) & ~(uintptr_t)255);
         uint16_t *rank16 = (uint16_t *)after;
         int32_t *seed = (int32_t *)(after + (((gn + 8 * (size_t)B) * 2 + 255) & ~(size_t)255));
-        bool logged = launch_unwrap_ranked(quality, mask, g0, g1, g2, g3, (int32_t *)g4, EN, rank16, seed, status, B, h, w, st, ev_flood, flood_tier);
+        bool logged = launch_unwrap_ranked(quality, mask, g0, g1, g2, g3, (int32_t *)g4, EN, rank16, seed, status, B, h, w, st, ev_flood, flood_tier, need);
         ppar = (const int32_t *)g4;
         if (logged) {
             if (ev_mid) hipEventRecord(ev_mid, st);
-            launch_unwrap_replay(wrapped, g2, 2 * EN, ppar, EN, parent, unwrapped, B, h, w, st);
+            launch_unwrap_replay(wrapped, g2, 2 * EN, ppar, EN, parent, unwrapped, B, h, w, st, need);
             return;
         }
     } else if (unwrap_big_supported(h, w) && flood_tier >= 2) {
@@ -266,24 +278,24 @@ void launch_unwrap(const float *wrapped, const float *quality, const uint8_t *ma
         if (ev_flood) hipEventRecord(ev_flood, st);
         launch_unwrap_flood_big(rank32, seed, nmask, g0, 2 * EN, (int32_t *)g4, EN, need_generic, flood_tier == 3, B, h, w, st);
         // (the generic kernel's frontier arrays reuse g0 | g1: the sorted indices are dead by now)
-        hipLaunchKernelGGL(k_unwrap_flood<false>, dim3(B), dim3(64), 0, st, quality, mask, parent, gst, g0, g1, P, status, h, w, need_generic);
+        hipLaunchKernelGGL(k_unwrap_flood<false>, dim3(B), dim3(64), 0, st, quality, mask, parent, gst, g0, g1, P, status, h, w, need_generic, need);
         if (ev_mid) hipEventRecord(ev_mid, st);
         hipLaunchKernelGGL(k_unwrap_tree, dim3(B), dim3(1024), 0, st, wrapped, parent, (const int32_t *)g4, EN, (unsigned long long *)g0, unwrapped, h, w,
-                           need_generic);
+                           need_generic, need);
         return;
     } else if (cap > 0) {
         if (ev_flood) hipEventRecord(ev_flood, st);
         static DynLdsOnce lds_once;
         ensure_dyn_lds(lds_once, (const void *)k_unwrap_flood<true>, 160 * 1024);
         size_t lds = (size_t)cap * 8 + ((P + 15) & ~15);
-        hipLaunchKernelGGL(k_unwrap_flood<true>, dim3(B), dim3(64), lds, st, quality, mask, parent, gst, g0, g1, cap, status, h, w, (const int32_t *)nullptr);
+        hipLaunchKernelGGL(k_unwrap_flood<true>, dim3(B), dim3(64), lds, st, quality, mask, parent, gst, g0, g1, cap, status, h, w, (const int32_t *)nullptr, need);
     } else {
         if (ev_flood) hipEventRecord(ev_flood, st);
-        hipLaunchKernelGGL(k_unwrap_flood<false>, dim3(B), dim3(64), 0, st, quality, mask, parent, gst, g0, g1, P, status, h, w, (const int32_t *)nullptr);
+        hipLaunchKernelGGL(k_unwrap_flood<false>, dim3(B), dim3(64), 0, st, quality, mask, parent, gst, g0, g1, P, status, h, w, (const int32_t *)nullptr, need);
     }
     if (ev_mid) hipEventRecord(ev_mid, st);
     // g0|g1 (2 x B*EN uint32, contiguous) hold the per-pixel 64-bit words; stride EN words per frame
-    hipLaunchKernelGGL(k_unwrap_tree, dim3(B), dim3(1024), 0, st, wrapped, parent, ppar, EN, (unsigned long long *)g0, unwrapped, h, w, (const int32_t *)nullptr);
+    hipLaunchKernelGGL(k_unwrap_tree, dim3(B), dim3(1024), 0, st, wrapped, parent, ppar, EN, (unsigned long long *)g0, unwrapped, h, w, (const int32_t *)nullptr, need);
 }
 
 }  // namespace vf

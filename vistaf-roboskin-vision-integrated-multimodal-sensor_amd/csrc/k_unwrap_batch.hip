@@ -44,8 +44,9 @@ __device__ inline int bt_scan_add(int v)
 
 __global__ __launch_bounds__(64) void k_unwrap_flood_batch(const uint16_t *__restrict__ rank_all, const int32_t *__restrict__ seed_in,
                                                            const uint32_t *__restrict__ inv_all, size_t inv_stride, int32_t *__restrict__ ppar_all,
-                                                           size_t gstride, uint32_t *__restrict__ order_all, size_t ostride, int h, int w, uint32_t magic)
+                                                           size_t gstride, uint32_t *__restrict__ order_all, size_t ostride, int h, int w, uint32_t magic, const int32_t *__restrict__ need_frame)
 {
+    if (need_frame && !need_frame[blockIdx.x]) return;        // the consistency check settled this frame (k_unwrap_fast.hip)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x;
     const size_t b = blockIdx.x;
@@ -263,8 +264,9 @@ constexpr int16_t RP_UNSET = (int16_t)0x7fff;
 __global__ __launch_bounds__(64 * RP_NW) void k_unwrap_replay(const float *__restrict__ wrapped_all, const uint32_t *__restrict__ order_all,
                                                               size_t ostride, const int32_t *__restrict__ ppar_all, size_t gstride,
                                                               int32_t *__restrict__ tree_all, float *__restrict__ unwrapped_all, int h, int w,
-                                                              uint32_t magic)
+                                                              uint32_t magic, const int32_t *__restrict__ need_frame)
 {
+    if (need_frame && !need_frame[blockIdx.x]) return;        // the consistency check settled this frame (k_unwrap_fast.hip)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     int16_t *ks = (int16_t *)lds_raw;                                     // [EN8]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -342,26 +344,26 @@ bool unwrap_batch_supported(int h, int w)
 }
 
 void launch_unwrap_flood_batch(const uint16_t *rank16, const int32_t *seed, const uint32_t *inv, size_t inv_stride, int32_t *ppar, size_t gstride,
-                               uint32_t *order, size_t ostride, int B, int h, int w, hipStream_t st)
+                               uint32_t *order, size_t ostride, int B, int h, int w, hipStream_t st, const int32_t *need)
 {
     long EN = (long)(h + 2) * (w + 2);
     size_t lds = (size_t)(((EN + 7) & ~7L)) * 2 + (BT_NW + 16) * 8 + 256 + 512;
     static DynLdsOnce lds_once;
         ensure_dyn_lds(lds_once, (const void *)k_unwrap_flood_batch, 160 * 1024);
     const uint32_t magic = (uint32_t)(0x100000000ull / (unsigned)(w + 2)) + 1u;     // idx / (w + 2) == umulhi(idx, magic) for idx < 65536
-    hipLaunchKernelGGL(k_unwrap_flood_batch, dim3(B), dim3(64), lds, st, rank16, seed, inv, inv_stride, ppar, gstride, order, ostride, h, w, magic);
+    hipLaunchKernelGGL(k_unwrap_flood_batch, dim3(B), dim3(64), lds, st, rank16, seed, inv, inv_stride, ppar, gstride, order, ostride, h, w, magic, need);
 }
 
 // unwrapped = wrapped + 2*pi*k along the growth tree; NaN / parent -1 where the growth never arrived
 void launch_unwrap_replay(const float *wrapped, const uint32_t *order, size_t ostride, const int32_t *ppar, size_t gstride, int32_t *tree,
-                          float *unwrapped, int B, int h, int w, hipStream_t st)
+                          float *unwrapped, int B, int h, int w, hipStream_t st, const int32_t *need)
 {
     long EN = (long)(h + 2) * (w + 2);
     size_t lds = (size_t)(((EN + 7) & ~7L)) * 2;
     static DynLdsOnce lds_once;
         ensure_dyn_lds(lds_once, (const void *)k_unwrap_replay, 160 * 1024);
     const uint32_t magic = (uint32_t)(0x100000000ull / (unsigned)(w + 2)) + 1u;
-    hipLaunchKernelGGL(k_unwrap_replay, dim3(B), dim3(64 * RP_NW), lds, st, wrapped, order, ostride, ppar, gstride, tree, unwrapped, h, w, magic);
+    hipLaunchKernelGGL(k_unwrap_replay, dim3(B), dim3(64 * RP_NW), lds, st, wrapped, order, ostride, ppar, gstride, tree, unwrapped, h, w, magic, need);
 }
 
 }  // namespace vf

@@ -37,8 +37,9 @@ constexpr int HOT_NW = 1024;   // 64-bit words of the code bitmap (codes < 65536
 
 __global__ __launch_bounds__(64) void k_unwrap_flood_hot(const uint16_t *__restrict__ rank_all, const int32_t *__restrict__ seed_in,
                                                          const uint32_t *__restrict__ inv_all, size_t inv_stride, int32_t *__restrict__ ppar_all,
-                                                         size_t gstride, int32_t *status, int h, int w)
+                                                         size_t gstride, int32_t *status, int h, int w, const int32_t *__restrict__ need_frame)
 {
+    if (need_frame && !need_frame[blockIdx.x]) return;        // the consistency check settled this frame (k_unwrap_fast.hip)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x;
     const size_t b = blockIdx.x;
@@ -199,13 +200,13 @@ bool unwrap_hot_supported(int h, int w)
 }
 
 void launch_unwrap_flood_hot(const uint16_t *rank16, const int32_t *seed, const uint32_t *inv, size_t inv_stride, int32_t *ppar, size_t gstride,
-                             int32_t *status, int B, int h, int w, hipStream_t st)
+                             int32_t *status, int B, int h, int w, hipStream_t st, const int32_t *need)
 {
     long EN = (long)(h + 2) * (w + 2);
     size_t lds = (size_t)(((EN + 7) & ~7L)) * 2 + (HOT_NW + 16) * 8 + 256;
     static DynLdsOnce lds_once;
         ensure_dyn_lds(lds_once, (const void *)k_unwrap_flood_hot, 160 * 1024);
-    hipLaunchKernelGGL(k_unwrap_flood_hot, dim3(B), dim3(64), lds, st, rank16, seed, inv, inv_stride, ppar, gstride, status, h, w);
+    hipLaunchKernelGGL(k_unwrap_flood_hot, dim3(B), dim3(64), lds, st, rank16, seed, inv, inv_stride, ppar, gstride, status, h, w, need);
 }
 
 }  // namespace vf

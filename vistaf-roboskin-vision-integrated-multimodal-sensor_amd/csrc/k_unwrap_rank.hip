@@ -22,9 +22,9 @@ namespace vf {
 bool unwrap_hot_supported(int h, int w);
 bool unwrap_batch_supported(int h, int w);
 void launch_unwrap_flood_batch(const uint16_t *rank16, const int32_t *seed, const uint32_t *inv, size_t inv_stride, int32_t *ppar, size_t gstride,
-                               uint32_t *order, size_t ostride, int B, int h, int w, hipStream_t st);
+                               uint32_t *order, size_t ostride, int B, int h, int w, hipStream_t st, const int32_t *need);
 void launch_unwrap_flood_hot(const uint16_t *rank16, const int32_t *seed, const uint32_t *inv, size_t inv_stride, int32_t *ppar, size_t gstride,
-                             int32_t *status, int B, int h, int w, hipStream_t st);
+                             int32_t *status, int B, int h, int w, hipStream_t st, const int32_t *need);
 
 constexpr int RK_T = 1024;
 
@@ -204,8 +204,9 @@ __device__ __attribute__((always_inline)) inline void unwrap_rank_body(const flo
 }
 __global__ __launch_bounds__(RK_T) void k_unwrap_rank(const float *__restrict__ quality_all, const uint8_t *__restrict__ mask_all,
                                                       unsigned long long *A_all, unsigned long long *B_all, size_t gstride,
-                                                      uint16_t *__restrict__ rank_all, int32_t *__restrict__ seed_out, int h, int w)
+                                                      uint16_t *__restrict__ rank_all, int32_t *__restrict__ seed_out, int h, int w, const int32_t *__restrict__ need_frame)
 {
+    if (need_frame && !need_frame[blockIdx.x]) return;        // the consistency check settled this frame (k_unwrap_fast.hip)
     unwrap_rank_body<uint16_t>(quality_all, mask_all, A_all, B_all, gstride, rank_all, seed_out, nullptr, h, w);
 }
 __global__ __launch_bounds__(RK_T) void k_unwrap_rank32(const float *__restrict__ quality_all, const uint8_t *__restrict__ mask_all,
@@ -229,8 +230,9 @@ void launch_unwrap_rank32(const float *quality, const uint8_t *mask, uint32_t *g
 // ppar[padded pixel] = padded index of its parent (own index for the seed), -1 where never reached
 __global__ __launch_bounds__(64) void k_unwrap_flood_ranked(const uint16_t *__restrict__ rank_all, const int32_t *__restrict__ seed_in,
                                                             int32_t *__restrict__ ppar_all, size_t gstride, int cap, int32_t *status,
-                                                            int h, int w)
+                                                            int h, int w, const int32_t *__restrict__ need_frame)
 {
+    if (need_frame && !need_frame[blockIdx.x]) return;        // the consistency check settled this frame (k_unwrap_fast.hip)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x;
     const size_t b = blockIdx.x;
@@ -349,7 +351,7 @@ bool unwrap_ranked_supported(int h, int w)
 // returns true when the growth kernel also left its pop records in g2 (stride 2 * gstride per frame) for launch_unwrap_replay
 bool launch_unwrap_ranked(const float *quality, const uint8_t *mask, uint32_t *g0, uint32_t *g1, uint32_t *g2, uint32_t *g3,
                           int32_t *ppar, size_t gstride, uint16_t *rank16, int32_t *seed, int32_t *status, int B, int h, int w,
-                          hipStream_t st, hipEvent_t ev_flood, int flood_tier)
+                          hipStream_t st, hipEvent_t ev_flood, int flood_tier, const int32_t *need)
 {
     int EN = (h + 2) * (w + 2);
     int cap = ranked_cap(EN);
@@ -358,7 +360,7 @@ bool launch_unwrap_ranked(const float *quality, const uint8_t *mask, uint32_t *g
     static DynLdsOnce rank_once;
     ensure_dyn_lds(rank_once, (const void *)k_unwrap_rank, 16 * RK_NB * (int)sizeof(uint32_t));   // + 64 B static
     hipLaunchKernelGGL(k_unwrap_rank, dim3(B), dim3(RK_T), (size_t)16 * RK_NB * sizeof(uint32_t), st, quality, mask, (unsigned long long *)g0,
-                       (unsigned long long *)g2, gstride, rank16, seed, h, w);
+                       (unsigned long long *)g2, gstride, rank16, seed, h, w, need);
     if (ev_flood) hipEventRecord(ev_flood, st);
     // growth loop (Tiers::flood): 2 = "batch" (default: 8 pops per step, k_unwrap_batch.hip), 1 = "hot" (one pop per step, sorted
     // register list + rank bitmap), 0 = "scan" (frontier array scan)
@@ -366,17 +368,17 @@ bool launch_unwrap_ranked(const float *quality, const uint8_t *mask, uint32_t *g
     if (use_hot == 2 && unwrap_batch_supported(h, w)) {
         // sorted pixel indices: g0 (stride 2 * gstride); the sort records in g2|g3 are dead once the ranks are out: the growth
         // kernel logs its pops there
-        launch_unwrap_flood_batch(rank16, seed, g0, 2 * gstride, ppar, gstride, g2, 2 * gstride, B, h, w, st);
+        launch_unwrap_flood_batch(rank16, seed, g0, 2 * gstride, ppar, gstride, g2, 2 * gstride, B, h, w, st, need);
         return true;
     }
     if (use_hot && unwrap_hot_supported(h, w)) {
-        launch_unwrap_flood_hot(rank16, seed, g0, 2 * gstride, ppar, gstride, status, B, h, w, st);
+        launch_unwrap_flood_hot(rank16, seed, g0, 2 * gstride, ppar, gstride, status, B, h, w, st, need);
         return false;
     }
     static DynLdsOnce lds_once;
     ensure_dyn_lds(lds_once, (const void *)k_unwrap_flood_ranked, 160 * 1024);
     size_t lds = (size_t)((EN + 7) & ~7) * 2 + (size_t)cap * 4;
-    hipLaunchKernelGGL(k_unwrap_flood_ranked, dim3(B), dim3(64), lds, st, rank16, seed, ppar, gstride, cap, status, h, w);
+    hipLaunchKernelGGL(k_unwrap_flood_ranked, dim3(B), dim3(64), lds, st, rank16, seed, ppar, gstride, cap, status, h, w, need);
     return false;
 }
 

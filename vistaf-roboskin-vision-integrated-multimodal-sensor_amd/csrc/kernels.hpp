@@ -15,6 +15,7 @@ struct Tiers {
     int chamfer_twopass = 0;    // 1: force the one-wave two-pass chamfer even where the LDS closed form applies
     int fit_capped = 1;        // 1: register-capped column polyfit (fits on a CU next to a march / flood wave); 0: 128-VGPR variant
     int telea_two_tier = 1;     // 1: 111 KB first tier of the window march + full-size retry of the frames it hands back; 0: full size only
+    int unwrap_fast = 1;        // 1: frames whose wrapped field is verified path-independent skip the priority flood (k_unwrap_fast.hip); 0: always flood
     int telea_mw = 1;           // 1: the 16-wave window kernel (ordering pass + dataflow fills, k_inpaint_mw.hip) as first tier, single-wave tiers behind it; 0: single-wave tiers only
 };
 
@@ -117,7 +118,7 @@ void launch_inpaint_clusters(float *img, const uint8_t *bad, int range, void *sc
 size_t unwrap_scratch_bytes_per_frame(int h, int w);
 void launch_unwrap(const float *wrapped, const float *quality, const uint8_t *mask, float *unwrapped, int32_t *parent,
                    void *scratch, int32_t *status, int B, int h, int w, hipStream_t st, hipEvent_t ev_mid,
-                   hipEvent_t ev_flood = nullptr, int flood_tier = 2);
+                   hipEvent_t ev_flood = nullptr, int flood_tier = 2, int32_t *need_buf = nullptr);      // need_buf [B]: enables the consistency check (k_unwrap_fast.hip)
 
 // ---- k_fit.hip --------------------------------------------------------------------------------
 // min_count: fitted (mask & finite) pixels needed (:1103); min_mask_count: mask pixels needed, NaN included (debug_ramp's own gate, :1364)

@@ -12,6 +12,8 @@ extern "C" {
  *                       bitmap flood hands every frame back to the generic kernel, as it does for masks larger than its bitmap
  *       "chamfer_twopass" 1 forces the one-wave two-pass chamfer transform
  *       "telea_two_tier" 1 (default) 111 KB first tier of the window march + full-size retry, 0 full-size march only
+ *       "unwrap_fast"  1 (default) frames whose wrapped field is verified path-independent take the parallel integration (k_unwrap_fast.hip)
+ *                      instead of the priority flood, 0 always the flood (the parent plane is only produced by the flood)
  *       "telea_mw"     1 (default) 16-wave window kernel (ordering pass + dataflow fills) in front of the single-wave tiers, 0 single-wave tiers only
  *       "fit_capped"   1 (default) register-capped column polyfit that shares a CU with a march / flood wave, 0 the 128-VGPR variant
  *       "keep_planes"   1 also writes the float64 demodulated field of every frame ("field" of vistaf_ftp_get_intermediate) */
