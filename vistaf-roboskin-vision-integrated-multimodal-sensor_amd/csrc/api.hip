@@ -17,7 +17,7 @@
 using namespace vf;
 #include "test_hooks.h"
 #ifdef VISTAF_DEBUG
-namespace vf { void telea_debug_dump(); void telea_window_debug_dump(int B); void telea_window_mw_debug_dump(int B); void unwrap_big_debug_dump(); void unwrap_batch_debug_dump(); }
+namespace vf { void telea_debug_dump(); void telea_window_debug_dump(int B); void telea_window_mw_debug_dump(int B); void fit_debug_dump(); void unwrap_big_debug_dump(); void unwrap_batch_debug_dump(); }
 #endif
 
 static thread_local std::string g_err;
@@ -673,7 +673,7 @@ static int post_demod(vistaf_ftp_handle *hd, int B, float *d_height_mm, uint8_t 
         for (int i = 0; i < ST_COUNT; i++) hipEventElapsedTime(&hd->stage_ms[i], hd->ev[i], hd->ev[i + 1]);
     }
 #ifdef VISTAF_DEBUG
-    if (getenv("VISTAF_TELEA_DBG")) { hipStreamSynchronize(st); telea_debug_dump(); telea_window_debug_dump(B); telea_window_mw_debug_dump(B); unwrap_big_debug_dump(); unwrap_batch_debug_dump(); }
+    if (getenv("VISTAF_TELEA_DBG")) { hipStreamSynchronize(st); telea_debug_dump(); telea_window_debug_dump(B); telea_window_mw_debug_dump(B); fit_debug_dump(); unwrap_big_debug_dump(); unwrap_batch_debug_dump(); }
 #endif
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VISTAF_E_HIP, std::string("launch: ") + hipGetErrorString(e));

@@ -10,9 +10,19 @@
 //
 // Every pass walks the plane itself (z f32 + mask u8 = 5 B/px, coordinates from two LDS tables) with
 // SEL_U / FIT_U independent loads in flight per thread: the passes are bound by memory round trips, not bytes.
+#include <cstdio>
 #include <algorithm>
 #include <type_traits>
 #include "kernels.hpp"
+#ifdef VISTAF_DEBUG
+// cycle sums of frame 0's fits (thread 0): [0] histogram clear, [1] histogram pass, [2] bucket search, [3] candidate collection, [4] sort,
+// [5] second order statistic by a pass, [6] column sums, [7] reduction + solve, [8] load, [9] residual plane, [10] launches
+namespace vf { __device__ unsigned long long g_fit_dbg[16]; __device__ unsigned long long g_fit_last; }
+#define SEL_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); vf::g_fit_dbg[i] += t_ - vf::g_fit_last; vf::g_fit_last = t_; } } while (0)
+#define FIT_START() do { if (blockIdx.x == 0 && threadIdx.x == 0) { vf::g_fit_last = __builtin_amdgcn_s_memtime(); vf::g_fit_dbg[10]++; } } while (0)
+#else
+#define FIT_START() do { } while (0)
+#endif
 #include "select.hpp"
 
 namespace vf {
@@ -312,7 +322,13 @@ __device__ __attribute__((always_inline)) inline void robust_polyfit_col_body(co
                                                               int iters, float c, int min_count, int min_mask_count, float *__restrict__ coef_out,
                                                               float *__restrict__ resid_all, int h, int w, int cols_pad, int groups_rt)
 {
+    // everything below that depends on the workgroup size takes it from NT (block reductions through 16-entry scratch arrays, NT / 64
+    // partial sums, the selection's NT-strided loops): the launcher must start exactly NT threads and derive the row groups from NT
+    static_assert(NT % 64 == 0 && NT >= 256 && NT / 64 <= 16, "block_sum / block_min / block_max scratch holds 16 waves");
+    static_assert(RP >= 1 && RP <= 128, "rows per thread live in registers");
+    static_assert(GT >= 0 && (GT == 0 || (RP - 1) * GT + GT + 15 < FIT_YTAB), "row table");
     const int groups = GT > 0 ? GT : groups_rt;
+    FIT_START();
     __shared__ SelShared sh;
     __shared__ double s_part[NT / 64][21];
     __shared__ double s_sum[21];
@@ -370,6 +386,7 @@ __device__ __attribute__((always_inline)) inline void robust_polyfit_col_body(co
     __syncthreads();
     const float zmin = key2f(zkmin), zmax = key2f(zkmax);
     const bool do_fit = (int)n >= min_count && (min_mask_count <= 0 || (int)cntm >= min_mask_count);
+    SEL_STAMP(8);
 
     float coef[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float At = 0.f, Bt = 0.f;          // fit(x, y) = At + yn * Bt + c5 * yn^2 for this thread's column
@@ -433,6 +450,7 @@ __device__ __attribute__((always_inline)) inline void robust_polyfit_col_body(co
                 for (int aa = 0; aa + bb <= 4; aa++) v21[k++] = xp[aa] * Pb[bb];     // k = index of (a, b), b-major
             v21[15] = x1 * Qb[0]; v21[16] = Qb[1]; v21[17] = Qb[0]; v21[18] = x2 * Qb[0]; v21[19] = x1 * Qb[1]; v21[20] = Qb[2];
         }
+        SEL_STAMP(6);
 #pragma unroll
         for (int i = 0; i < 21; i++) {
             const double v = wave_sum(v21[i]);
@@ -464,6 +482,7 @@ __device__ __attribute__((always_inline)) inline void robust_polyfit_col_body(co
         for (int i = 0; i < 6; i++) coef[i] = s_coef[i];
         At = fmaf(coef[3], __fmul_rn(xn, xn), fmaf(coef[0], xn, coef[2]));
         Bt = fmaf(coef[4], xn, coef[1]);
+        SEL_STAMP(7);
         if (it == iters - 1) break;   // the weights of the last iteration are never used upstream
         // ---- sigma = 1.4826 * (median |r - median r| + 1e-6); the value ranges come from bounds on |fit| (|xn|, |yn| <= 1)
         uint32_t kmin, kmax;
@@ -510,7 +529,18 @@ __device__ __attribute__((always_inline)) inline void robust_polyfit_col_body(co
             out[(size_t)y * w + col] = __fsub_rn(zin, fit);
         }
     }
+    SEL_STAMP(9);
 }
+
+#ifdef VISTAF_DEBUG
+void fit_debug_dump()
+{
+    unsigned long long d[16];
+    if (hipMemcpyFromSymbol(d, HIP_SYMBOL(g_fit_dbg), sizeof(d)) != hipSuccess) return;
+    printf("[fit dbg] frame 0, %llu launches so far, cycle sums: load %llu | column sums %llu | reduce+solve %llu | hist clear %llu | hist pass %llu | bucket search %llu | "
+           "collect %llu | sort %llu | second statistic pass %llu | residual plane %llu\n", d[10], d[8], d[6], d[7], d[0], d[1], d[2], d[3], d[4], d[5], d[9]);
+}
+#endif
 
 #define VF_FIT_ARGS const float *__restrict__ z_all, const uint8_t *__restrict__ mask_all, int order, int iters, float c, int min_count, int min_mask_count, \
                     float *__restrict__ coef_out, float *__restrict__ resid_all, int h, int w, int cols_pad, int groups
@@ -534,7 +564,8 @@ void launch_robust_polyfit(const float *z, const uint8_t *mask, int order, int i
     const uint32_t magic = ((unsigned long long)h * w * w < 0x100000000ull) ? (uint32_t)(0x100000000ull / (unsigned)w) + 1u : 0u;
     const int cols_pad = ((w + 63) / 64) * 64;
 #define VF_FIT_COL(KERNEL, NTV, GR) hipLaunchKernelGGL(KERNEL, dim3(B), dim3(NTV), 0, st, z, mask, order, iters, c, min_count, min_mask_count, coef_out, resid_out, h, w, cols_pad, GR)
-    const int groups = cols_pad <= SEL_T ? std::min(SEL_T / cols_pad, h) : 0;
+    constexpr int NT = SEL_T;                      // threads of every column kernel below (robust_polyfit_col_body's NT): the row groups follow from it
+    const int groups = cols_pad <= NT ? std::min(NT / cols_pad, h) : 0;
     const int need = groups ? (h + groups - 1) / groups : 1 << 30;
     if (need <= 64 && h + groups * 16 <= FIT_YTAB) {
         if (capped == 1 && groups == 4 && need > 48 && need <= 56) VF_FIT_COL((k_robust_polyfit_col_w5<56, 4>), SEL_T, 4);

@@ -13,7 +13,7 @@ struct Tiers {
     int inpaint = 2;            // 2: frame-window march (k_telea_window) + whole-frame fallback; 1: whole-frame kernel only; 0: cluster front end first
     int flood = 2;              // 2: batched pops (k_unwrap_flood_batch / k_unwrap_flood_big); 1: one pop per step (k_unwrap_flood_hot); 0: frontier scan; 3: test only (test_hooks.h)
     int chamfer_twopass = 0;    // 1: force the one-wave two-pass chamfer even where the LDS closed form applies
-    int fit_capped = 1;        // 1: register-capped column polyfit (fits on a CU next to a march / flood wave); 0: 128-VGPR variant
+    int fit_capped = 0;        // 0: 128-VGPR column polyfit (default since the march and the flood stopped pinning CUs for milliseconds: 1.49 against 1.79 ms per step); 1: register-capped variant (96 VGPRs, shares a CU with LDS-heavy one-wave kernels)
     int telea_two_tier = 1;     // 1: 111 KB first tier of the window march + full-size retry of the frames it hands back; 0: full size only
     int unwrap_fast = 1;        // 1: frames whose wrapped field is verified path-independent skip the priority flood (k_unwrap_fast.hip); 0: always flood
     int telea_mw = 1;           // 1: the 16-wave window kernel (ordering pass + dataflow fills, k_inpaint_mw.hip) as first tier, single-wave tiers behind it; 0: single-wave tiers only

@@ -11,6 +11,10 @@
 
 namespace vf {
 
+#ifndef SEL_STAMP
+#define SEL_STAMP(i) do { } while (0)      // diagnostics hook (k_fit.hip, -DVISTAF_DEBUG)
+#endif
+
 constexpr int SEL_T = 1024;
 constexpr int SEL_BITS = 13;          // histogram digits: 8192 buckets, 8 per thread in the bucket search
 constexpr int SEL_NB = 1 << SEL_BITS;
@@ -78,8 +82,10 @@ __device__ __attribute__((always_inline)) inline void block_select2_each(Each ea
         int shift = bits > SEL_BITS ? bits - SEL_BITS : 0;
         for (int i = tid; i < SEL_NB; i += NT) sh.hist[i] = 0;
         __syncthreads();
+        SEL_STAMP(0);
         each([&](uint32_t key) { if (key >= lo && key <= hi) atomicAdd(&sh.hist[(key - lo) >> shift], 1u); });
         __syncthreads();
+        SEL_STAMP(1);
         // locate the bucket holding rank (k - below): each thread owns SEL_NB / SEL_T consecutive buckets
         uint32_t want = k - below;
         constexpr int NBT = SEL_NB / NT;
@@ -111,6 +117,7 @@ __device__ __attribute__((always_inline)) inline void block_select2_each(Each ea
         if (nhi > hi || nhi < nlo) nhi = hi;
         lo = nlo; hi = nhi;
         __syncthreads();
+        SEL_STAMP(2);
         if (shift == 0) { a = lo; break; }
         if (cnt <= CAND) {
             // collect candidates of this bucket, rank by counting
@@ -130,6 +137,7 @@ __device__ __attribute__((always_inline)) inline void block_select2_each(Each ea
                 }
             });
             __syncthreads();
+            SEL_STAMP(3);
             uint32_t m = sh.s_ncand;
             const uint32_t want2 = k - below;
             if (tid == 0) { sh.s_found = 0; }
@@ -158,6 +166,7 @@ __device__ __attribute__((always_inline)) inline void block_select2_each(Each ea
                 if (want2 + 1 < m) { sh.s_b = sh.cand[want2 + 1]; sh.s_found = 1; }
             }
             __syncthreads();
+            SEL_STAMP(4);
             a = sh.s_a;
             if (sh.s_found) { key_a = a; key_b = sh.s_b; __syncthreads(); return; }
             break;
@@ -173,6 +182,7 @@ __device__ __attribute__((always_inline)) inline void block_select2_each(Each ea
         unsigned long long mn = block_min_u64(nxt, sh.red64);
         b = (k + 1 < tot || mn == ~0ull) ? a : (uint32_t)mn;
         __syncthreads();
+        SEL_STAMP(5);
     }
     key_a = a; key_b = b;
 }

@@ -15,7 +15,7 @@ extern "C" {
  *       "unwrap_fast"  1 (default) frames whose wrapped field is verified path-independent take the parallel integration (k_unwrap_fast.hip)
  *                      instead of the priority flood, 0 always the flood (the parent plane is only produced by the flood)
  *       "telea_mw"     1 (default) 16-wave window kernel (ordering pass + dataflow fills) in front of the single-wave tiers, 0 single-wave tiers only
- *       "fit_capped"   1 (default) register-capped column polyfit that shares a CU with a march / flood wave, 0 the 128-VGPR variant
+ *       "fit_capped"   0 (default) the 128-VGPR column polyfit, 1 the register-capped variant (96 VGPRs) that shares a CU with LDS-heavy one-wave kernels
  *       "keep_planes"   1 also writes the float64 demodulated field of every frame ("field" of vistaf_ftp_get_intermediate) */
 int vistaf_ftp_test_set(vistaf_ftp_handle *hd, const char *name, int value);
 #ifdef __cplusplus
