@@ -210,8 +210,15 @@ def test_big_frame_flood_reproduces_the_heap_order(pkg, cal):
     cfg = pkg.FtpConfig.scaled(n)
     ref, sensor = _sensor(pkg, cal, n, cfg, nb, config=5)
     frames = pkg.synth.deformed_batch(n, 0, nb, config=5, amp_scale=9.0)
+    # with the consistency check on (the default) these path-independent frames never reach the flood; its plane is kept for comparison
+    sensor.predict_batch(frames)
+    torch.cuda.synchronize()
+    assert (sensor.intermediate("unwrap_need", nb, torch.int32).cpu().numpy() == 0).all()
+    uw_check = sensor.intermediate("unwrapped", nb).cpu().numpy().copy()
+    sensor._test_set("unwrap_fast", 0)
     out = sensor.predict_batch(frames)
     torch.cuda.synchronize()
+    assert np.array_equal(sensor.intermediate("unwrapped", nb).cpu().numpy(), uw_check, equal_nan=True)
     rs = O.make_reference_state(ref, *pkg.synth.roi_circle(n), cfg)
     P = n * n
     uw_all = sensor.intermediate("unwrapped", nb).cpu().numpy().copy()

@@ -35,8 +35,8 @@ struct GKern { float *d = nullptr; int k = 0; };
 
 enum Stage { ST_GRAY_BAD = 0, ST_INPAINT, ST_PREPROC, ST_DEMOD, ST_RELIABLE, ST_UNWRAP_RANK, ST_UNWRAP, ST_UNWRAP_TREE, ST_DETREND, ST_SMOOTH_FLIP, ST_COMPOSE, ST_MM_BLOB,
              ST_TAIL, ST_COUNT };
-const char *kStageNames[ST_COUNT] = {"gray+badpix", "inpaint (k_telea_window)", "illum+blur+apod+median", "pruned-dft demod", "reliable mask",
-                                     "unwrap rank (k_unwrap_rank)", "unwrap flood (k_unwrap_flood_batch)", "unwrap tree", "detrend (3x IRLS)", "smooth+flip", "frontier+compose", "mm+blob filter", "tail"};
+const char *kStageNames[ST_COUNT] = {"gray+badpix", "inpaint (k_telea_window_mw)", "illum+blur+apod+median", "pruned-dft demod", "reliable mask",
+                                     "unwrap check (k_unwrap_fast)", "unwrap flood (fallback)", "unwrap tree (fallback)", "detrend (3x IRLS)", "smooth+flip", "frontier+compose", "mm+blob filter", "tail"};
 
 int cv_round(double v) { return (int)std::nearbyint(v); }
 

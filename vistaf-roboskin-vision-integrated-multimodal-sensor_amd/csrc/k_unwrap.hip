@@ -205,12 +205,16 @@ __global__ __launch_bounds__(1024) void k_unwrap_tree(const float *__restrict__ 
     }
 }
 
-size_t unwrap_scratch_bytes_per_frame(int h, int w)
+size_t unwrap_fast_scratch_bytes_per_frame(int h, int w);
+static size_t unwrap_flood_scratch_bytes_per_frame(int h, int w)
 {
     size_t P = (size_t)h * w, EN = (size_t)(h + 2) * (w + 2);
     const size_t code_bytes = EN > 65533 ? 4 * EN + 32 : 2 * EN + 16;     // uint32 rank codes for frames beyond the uint16 range
-    return P /*st*/ + 5 * EN * sizeof(uint32_t) /*sort / frontier / jump buffers / padded parents*/ + code_bytes /*rank codes*/ + 64 /*seed, n, flag*/ + 512;
+    return P /*st*/ + 5 * EN * sizeof(uint32_t) /*sort / frontier / jump buffers / padded parents*/ + code_bytes /*rank codes*/ + 64 /*seed, n, flag*/ + 1536 /*alignment of the sub-planes, also for a batch of one*/;
 }
+
+// the flood's planes for B frames come first, the consistency check's (k_unwrap_fast.hip) behind them
+size_t unwrap_scratch_bytes_per_frame(int h, int w) { return unwrap_flood_scratch_bytes_per_frame(h, w) + unwrap_fast_scratch_bytes_per_frame(h, w) + 16; }
 
 bool unwrap_ranked_supported(int h, int w);
 bool launch_unwrap_ranked(const float *quality, const uint8_t *mask, uint32_t *g0, uint32_t *g1, uint32_t *g2, uint32_t *g3,
@@ -220,11 +224,12 @@ void launch_unwrap_replay(const float *wrapped, const uint32_t *order, size_t os
                           float *unwrapped, int B, int h, int w, hipStream_t st, const int32_t *need);
 bool unwrap_big_supported(int h, int w);
 bool unwrap_fast_supported(int h, int w);
-void launch_unwrap_fast(const float *wrapped, const float *quality, const uint8_t *mask, float *unwrapped, int32_t *need, int B, int h, int w, hipStream_t st);
+void launch_unwrap_fast(const float *wrapped, const float *quality, const uint8_t *mask, float *unwrapped, int32_t *need, void *scratch, int B, int h, int w,
+                        hipStream_t st);
 void launch_unwrap_rank32(const float *quality, const uint8_t *mask, uint32_t *gA, uint32_t *gB, size_t gstride, uint32_t *rank32, int32_t *seed,
-                          int32_t *n_out, int B, int h, int w, hipStream_t st);
+                          int32_t *n_out, int B, int h, int w, hipStream_t st, const int32_t *need);
 void launch_unwrap_flood_big(uint32_t *code, const int32_t *seed, const int32_t *n, const uint32_t *inv, size_t inv_stride, int32_t *ppar,
-                             size_t gstride, int32_t *need_generic, bool force_generic, int B, int h, int w, hipStream_t st);
+                             size_t gstride, int32_t *need_generic, bool force_generic, int B, int h, int w, hipStream_t st, const int32_t *need);
 
 static int unwrap_lds_cap(int P)
 {
@@ -251,7 +256,8 @@ void launch_unwrap(const float *wrapped, const float *quality, const uint8_t *ma
     // such a frame is not produced (it is a by-product of the flood; the parity tests that compare trees switch the check off).
     const int32_t *need = nullptr;
     if (need_buf && unwrap_fast_supported(h, w)) {
-        launch_unwrap_fast(wrapped, quality, mask, unwrapped, need_buf, B, h, w, st);
+        void *fs = (void *)(((uintptr_t)scratch + unwrap_flood_scratch_bytes_per_frame(h, w) * (size_t)B + 255) & ~(uintptr_t)255);
+        launch_unwrap_fast(wrapped, quality, mask, unwrapped, need_buf, fs, B, h, w, st);
         need = need_buf;
     }
     if (unwrap_ranked_supported(h, w)) {
@@ -274,9 +280,9 @@ void launch_unwrap(const float *wrapped, const float *quality, const uint8_t *ma
         uint32_t *rank32 = (uint32_t *)after;
         int32_t *seed = (int32_t *)(after + (((gn + 8 * (size_t)B) * 4 + 255) & ~(size_t)255));
         int32_t *nmask = seed + B, *need_generic = nmask + B;
-        launch_unwrap_rank32(quality, mask, g0, g2, EN, rank32, seed, nmask, B, h, w, st);
+        launch_unwrap_rank32(quality, mask, g0, g2, EN, rank32, seed, nmask, B, h, w, st, need);
         if (ev_flood) hipEventRecord(ev_flood, st);
-        launch_unwrap_flood_big(rank32, seed, nmask, g0, 2 * EN, (int32_t *)g4, EN, need_generic, flood_tier == 3, B, h, w, st);
+        launch_unwrap_flood_big(rank32, seed, nmask, g0, 2 * EN, (int32_t *)g4, EN, need_generic, flood_tier == 3, B, h, w, st, need);
         // (the generic kernel's frontier arrays reuse g0 | g1: the sorted indices are dead by now)
         hipLaunchKernelGGL(k_unwrap_flood<false>, dim3(B), dim3(64), 0, st, quality, mask, parent, gst, g0, g1, P, status, h, w, need_generic, need);
         if (ev_mid) hipEventRecord(ev_mid, st);

@@ -43,8 +43,9 @@ __device__ unsigned long long g_big_dbg[8];        // frame 0: steps, candidates
 __global__ __launch_bounds__(64) void k_unwrap_flood_big(uint32_t *__restrict__ code_all, const int32_t *__restrict__ seed_in,
                                                          const int32_t *__restrict__ n_in, const uint32_t *__restrict__ inv_all, size_t inv_stride,
                                                          int32_t *__restrict__ ppar_all, size_t gstride, int32_t *__restrict__ need_generic, int max_ranks,
-                                                         int nw0, int h, int w, uint32_t magic)
+                                                         int nw0, int h, int w, uint32_t magic, const int32_t *__restrict__ need_frame)
 {
+    if (need_frame && !need_frame[blockIdx.x]) return;        // the consistency check settled this frame (k_unwrap_fast.hip)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     // nw0 words of L0 (sized by the host for the frame: every mask pixel can be a rank), then the two summary levels
     const int nw1 = (nw0 + 63) >> 6, nw2 = (nw1 + 63) >> 6;
@@ -231,7 +232,7 @@ bool unwrap_big_supported(int h, int w)
 
 // force_generic (test hook flood_tier = 3): hand every frame back, which exercises the per-frame fallback plumbing at small sizes
 void launch_unwrap_flood_big(uint32_t *code, const int32_t *seed, const int32_t *n, const uint32_t *inv, size_t inv_stride, int32_t *ppar,
-                             size_t gstride, int32_t *need_generic, bool force_generic, int B, int h, int w, hipStream_t st)
+                             size_t gstride, int32_t *need_generic, bool force_generic, int B, int h, int w, hipStream_t st, const int32_t *need)
 {
     // the bitmap is sized for the frame (at most one rank per pixel), up to the 150 KB of BG_NW0 words: mid-size frames leave LDS to others
     const long P = (long)h * w;
@@ -243,7 +244,7 @@ void launch_unwrap_flood_big(uint32_t *code, const int32_t *seed, const int32_t 
     static DynLdsOnce lds_once;
     ensure_dyn_lds(lds_once, (const void *)k_unwrap_flood_big, 160 * 1024);
     hipLaunchKernelGGL(k_unwrap_flood_big, dim3(B), dim3(64), lds, st, code, seed, n, inv, inv_stride, ppar, gstride, need_generic,
-                       force_generic ? 0 : nw0 * 64, nw0, h, w, magic);
+                       force_generic ? 0 : nw0 * 64, nw0, h, w, magic, need);
 }
 
 }  // namespace vf

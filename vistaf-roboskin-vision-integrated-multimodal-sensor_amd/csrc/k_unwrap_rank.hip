@@ -212,18 +212,19 @@ __global__ __launch_bounds__(RK_T) void k_unwrap_rank(const float *__restrict__ 
 __global__ __launch_bounds__(RK_T) void k_unwrap_rank32(const float *__restrict__ quality_all, const uint8_t *__restrict__ mask_all,
                                                         unsigned long long *A_all, unsigned long long *B_all, size_t gstride,
                                                         uint32_t *__restrict__ rank_all, int32_t *__restrict__ seed_out, int32_t *__restrict__ n_out,
-                                                        int h, int w)
+                                                        int h, int w, const int32_t *__restrict__ need_frame)
 {
+    if (need_frame && !need_frame[blockIdx.x]) return;        // the consistency check settled this frame (k_unwrap_fast.hip)
     unwrap_rank_body<uint32_t>(quality_all, mask_all, A_all, B_all, gstride, rank_all, seed_out, n_out, h, w);
 }
 // ranks of frames too large for uint16 codes: 32-bit codes in a padded plane, sorted pixel indices in A (uint32, stride 2 * gstride)
 void launch_unwrap_rank32(const float *quality, const uint8_t *mask, uint32_t *gA, uint32_t *gB, size_t gstride, uint32_t *rank32, int32_t *seed,
-                          int32_t *n_out, int B, int h, int w, hipStream_t st)
+                          int32_t *n_out, int B, int h, int w, hipStream_t st, const int32_t *need)
 {
     static DynLdsOnce rank_once;
     ensure_dyn_lds(rank_once, (const void *)k_unwrap_rank32, 16 * RK_NB * (int)sizeof(uint32_t));
     hipLaunchKernelGGL(k_unwrap_rank32, dim3(B), dim3(RK_T), (size_t)16 * RK_NB * sizeof(uint32_t), st, quality, mask, (unsigned long long *)gA,
-                       (unsigned long long *)gB, gstride, rank32, seed, n_out, h, w);
+                       (unsigned long long *)gB, gstride, rank32, seed, n_out, h, w, need);
 }
 
 // ---- growth --------------------------------------------------------------------------------------------
