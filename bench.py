@@ -206,6 +206,7 @@ def main():
                     help="sessions (each with its own HIP stream and workspace) that take the steps in turn, so consecutive steps overlap on the GPU; "
                          "1 = strictly serial steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the two extra figures measured after the timed region (constants as shipped, configs[1]): profiling runs")
     ap.add_argument("--kernel-tier", action="append", default=[], metavar="NAME=VALUE",
                     help="diagnostic A/B runs: kernel tier hooks of csrc/test_hooks.h (e.g. telea_two_tier=0); the default run sets none")
     ap.add_argument("--cpu-budget-s", type=float, default=16.0)
@@ -295,7 +296,7 @@ def main():
     #  * the same batch with the reference's constants AS SHIPPED (pixel constants not rescaled from 1182 to this frame size);
     #  * BASELINE configs[1] as the survey restates it: batch 64, the demodulation stage alone (the path's only dense contraction).
     extra = {}
-    if rank == 0 and world == 1 and not args.pairs and not args.kernel_tier:
+    if rank == 0 and world == 1 and not args.pairs and not args.kernel_tier and not args.no_extras and n == 224:
         other_const = "shipped" if args.constants == "scaled" else "scaled"
         cfg2 = pkg.FtpConfig.as_shipped() if other_const == "shipped" else pkg.FtpConfig.scaled(n)
         sensors2 = [pkg.FtpSensor(ref3, pkg.synth.roi_circle(n), cfg2, cal, neg, fm, max_batch=B, device=dev) for _ in sensors]

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
 rm -rf $R/gpurun_out/prof_$tag   # (delete the locally merged copies of earlier runs with this tag too before reading new ones)
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --inflight 1 "$@" > $R/gpurun_out/prof_$tag.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras --inflight 1 "$@" > $R/gpurun_out/prof_$tag.log 2>&1
 echo prof_exit=$?
 f=$(find $R/gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'

@@ -5,10 +5,10 @@ tag=$1
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
-rm -rf $R/gpurun_out/pmc_${tag}_*   # (delete the locally merged copies of earlier runs with this tag too before reading new ones)
+rm -rf $R/gpurun_out/pmc_${tag}_FETCH_SIZE $R/gpurun_out/pmc_${tag}_WRITE_SIZE   # (delete the locally merged copies of earlier runs with this tag too before reading new ones)
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_${tag}_$c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --inflight 1 > $R/gpurun_out/pmc_${tag}_$c.log 2>&1
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_${tag}_$c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --inflight 1 > $R/gpurun_out/pmc_${tag}_$c.log 2>&1
   echo pmc_${c}_exit=$?
 done
 python3 - $R/gpurun_out $tag <<'PY'
