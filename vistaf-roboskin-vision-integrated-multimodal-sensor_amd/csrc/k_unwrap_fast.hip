@@ -14,7 +14,7 @@
 //                            flood never reaches do) -- one workgroup per frame, run table and edges in LDS when they fit;
 //   k_uf_absolute            absolute k per pixel;
 //   k_uf_verify              EVERY vertical and diagonal pair is checked against the equation above (the horizontal ones hold by construction);
-//                            a pair within 1e-9 of the branch cut, where c depends on the direction the tree crosses it, counts as a failure;
+//                            a pair within 1e-5 of the branch cut, where c depends on the direction the tree crosses it, counts as a failure;
 //   k_uf_plane               frames that passed get their plane and need[b] = 0; any other frame gets need[b] = 1 and goes through the exact
 //                            priority flood (k_unwrap_rank + k_unwrap_flood_* + k_unwrap_replay / k_unwrap_tree), whose kernels skip need[b] = 0.
 // The reliable mask (amplitude >= p25, closed, largest component, eroded) is residue-free on every frame looked at: the synthetic bench frames
@@ -28,7 +28,6 @@
 namespace vf {
 
 constexpr uint32_t UF_KNOWN = 0x80000000u;
-constexpr int UF_ROWS = 4;            // rows (= waves) per workgroup of the row kernels
 constexpr int UF_CH = 4;              // 64-pixel chunks of a row in flight per wave
 constexpr int UF_PASSES = 8;          // sweeps over the edge list between two barriers of the offset propagation
 constexpr int UF_LDS_RUNS = 6144, UF_LDS_EDGES = 12288;      // propagation in LDS: 4 B per run + 6 B per edge = 96 KB
@@ -48,19 +47,27 @@ struct UfPlanes {
     int rcap, ecap;
 };
 
-// c(a -> b): the integer k that brings d = w[b] - w[a] into (-pi, pi], i.e. what k_unwrap_tree's  k = -rint(d / 2 pi), one correction step
-// yields.  Formed with a multiplication by 1 / (2 pi) instead of the float64 division (four of these per pixel): the candidate may differ
-// from the division's only when d / 2 pi is within an ulp of a half-integer, i.e. when d + 2 pi k sits on the branch cut, and every pair
-// within 1e-9 of the cut is reported as a tie (the frame then takes the flood) -- wherever the result is USED it equals k_unwrap_tree's.
+// c(a -> b): the integer k that brings d = w[b] - w[a] into (-pi, pi], i.e. what k_unwrap_tree's float64  k = -rint(d / 2 pi) + one correction
+// step yields.  The wrapped plane comes from atan2, so |d| <= 2 pi and k is -1, 0 or +1: decided here by comparing the float32 difference
+// with pi (four of these per pixel: the float64 form made the check VALU-bound).  The float32 subtraction is off by at most 2^-23 |d| < 8e-7,
+// so the decision can differ from the float64 one only for pairs within 8e-7 of the branch cut -- and every pair within 1e-5 of the cut is
+// reported as a tie (the frame then takes the flood), which also covers the pairs exactly on the cut, where c depends on the direction the
+// tree crosses them.  Wherever this function's result is USED it equals k_unwrap_tree's.  (|d| beyond 2 pi + slack: the float64 form.)
 __device__ inline int uf_c(float wa, float wb, bool &tie)
 {
+    const float d = __fsub_rn(wb, wa), ad = fabsf(d);
+    const float pi_f = 3.14159274f;
+    if (ad < 6.4f) {
+        tie = tie || fabsf(ad - pi_f) < 1e-5f;
+        return ad > pi_f ? (d > 0.f ? -1 : 1) : 0;
+    }
     const double twopi = 6.283185307179586476925286766559, pi_d = 3.14159265358979323846, inv2pi = 0.15915494309189533576888376337251;
-    const double d = (double)wb - (double)wa;
-    double k = -rint(d * inv2pi);
-    double dd = d + twopi * k;
+    const double dd0 = (double)wb - (double)wa;
+    double k = -rint(dd0 * inv2pi);
+    double dd = dd0 + twopi * k;
     if (dd <= -pi_d) { k += 1.0; dd += twopi; }
     else if (dd > pi_d) { k -= 1.0; dd -= twopi; }
-    tie = tie || fabs(fabs(dd) - pi_d) < 1e-9;
+    tie = tie || fabs(fabs(dd) - pi_d) < 1e-5;
     return (int)k;
 }
 
@@ -89,15 +96,15 @@ __device__ inline uint32_t uf_prev_lane(uint32_t v, uint32_t first, int lane)
 }
 
 // ---- runs per row, seed.  Every wave of the row kernels takes rw consecutive rows (small frames: fewer, longer-lived waves)
-__global__ __launch_bounds__(64 * UF_ROWS) void k_uf_count(const float *__restrict__ quality_all, const uint8_t *__restrict__ mask_all, UfPlanes U, int h, int w, int rw)
+__global__ __launch_bounds__(1024) void k_uf_count(const float *__restrict__ quality_all, const uint8_t *__restrict__ mask_all, UfPlanes U, int h, int w, int rw)
 {
-    __shared__ unsigned long long s_best[UF_ROWS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ unsigned long long s_best[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
     const size_t b = blockIdx.y;
     const size_t P = (size_t)h * w;
     unsigned long long best = 0;
     for (int r = 0; r < rw; r++) {
-        const int y = (blockIdx.x * UF_ROWS + wave) * rw + r;
+        const int y = (blockIdx.x * nwv + wave) * rw + r;
         if (y >= h) break;
         const float *q = quality_all + b * P + (size_t)y * w;
         const uint8_t *m = mask_all + b * P + (size_t)y * w;
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(64 * UF_ROWS) void k_uf_count(const float *__restri
     if (lane == 0) s_best[wave] = best;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int i = 1; i < UF_ROWS; i++) best = s_best[i] > best ? s_best[i] : best;
+        for (int i = 1; i < nwv; i++) best = s_best[i] > best ? s_best[i] : best;
         if (best) atomicMax(&U.seedkey[b], best);
     }
 }
@@ -162,9 +169,9 @@ __global__ __launch_bounds__(1024) void k_uf_scan(UfPlanes U, int h)
 }
 
 // ---- k along the rows, relative to the first pixel of the run; run table
-__global__ __launch_bounds__(64 * UF_ROWS) void k_uf_rows(const float *__restrict__ wrapped_all, const uint8_t *__restrict__ mask_all, UfPlanes U, int h, int w, int rw)
+__global__ __launch_bounds__(1024) void k_uf_rows(const float *__restrict__ wrapped_all, const uint8_t *__restrict__ mask_all, UfPlanes U, int h, int w, int rw)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
     const size_t b = blockIdx.y;
     if (U.ctl[b * UFC_N + UFC_FAIL]) return;
     const size_t P = (size_t)h * w;
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(64 * UF_ROWS) void k_uf_rows(const float *__restric
     const unsigned long long le_mask = lane == 63 ? ~0ull : (2ull << lane) - 1ull;
     bool bad = false;
     for (int r = 0; r < rw; r++) {
-    const int y = (blockIdx.x * UF_ROWS + wave) * rw + r;
+    const int y = (blockIdx.x * nwv + wave) * rw + r;
     if (y >= h) break;
     const float *wr = wrapped_all + b * P + (size_t)y * w;
     const uint8_t *m = mask_all + b * P + (size_t)y * w;
@@ -232,9 +239,9 @@ __global__ __launch_bounds__(64 * UF_ROWS) void k_uf_rows(const float *__restric
 // stretch where both rows are in the mask (such a stretch lies in one run above and one run below), and the two diagonal ones
 // (U[x-1], D[x]) / (U[x], D[x-1]), emitted only where no vertical pair touches them (the two runs then meet corner to corner and nowhere
 // else).  Every pair of 8-adjacent runs gets exactly one edge; a run's number is its row's first run + the run starts seen so far.
-__global__ __launch_bounds__(64 * UF_ROWS) void k_uf_edges(const float *__restrict__ wrapped_all, UfPlanes U, int h, int w, int rw)
+__global__ __launch_bounds__(1024) void k_uf_edges(const float *__restrict__ wrapped_all, UfPlanes U, int h, int w, int rw)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
     const size_t b = blockIdx.y;
     if (U.ctl[b * UFC_N + UFC_FAIL]) return;
     const size_t P = (size_t)h * w;
@@ -245,7 +252,7 @@ __global__ __launch_bounds__(64 * UF_ROWS) void k_uf_edges(const float *__restri
     int32_t *nedge = &U.ctl[b * UFC_N + UFC_NEDGE];
     bool bad = false;
     for (int r = 0; r < rw; r++) {
-        const int y = (blockIdx.x * UF_ROWS + wave) * rw + r;
+        const int y = (blockIdx.x * nwv + wave) * rw + r;
         if (y >= h) break;
         const bool up = y > 0;
         const float *wD = wrapped_all + b * P + (size_t)y * w, *wU = wD - w;
@@ -353,16 +360,16 @@ __global__ __launch_bounds__(1024) void k_uf_propagate(UfPlanes U)
 }
 
 // ---- absolute k of every reached pixel (-127: in the mask but never reached)
-__global__ __launch_bounds__(64 * UF_ROWS) void k_uf_absolute(UfPlanes U, int h, int w, int rw)
+__global__ __launch_bounds__(1024) void k_uf_absolute(UfPlanes U, int h, int w, int rw)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
     const size_t b = blockIdx.y;
     if (U.ctl[b * UFC_N + UFC_FAIL]) return;
     const uint32_t *rstate = U.rstate + b * (size_t)U.rcap;
     const unsigned long long le_mask = lane == 63 ? ~0ull : (2ull << lane) - 1ull;
     bool bad = false;
     for (int r = 0; r < rw; r++) {
-    const int y = (blockIdx.x * UF_ROWS + wave) * rw + r;
+    const int y = (blockIdx.x * nwv + wave) * rw + r;
     if (y >= h) break;
     int8_t *kk = U.kk + b * U.P16 + (size_t)y * w;
     const int rb = U.rowbase[b * U.hp + y];
@@ -395,15 +402,15 @@ __global__ __launch_bounds__(64 * UF_ROWS) void k_uf_absolute(UfPlanes U, int h,
 }
 
 // ---- every vertical and diagonal pair of the reached component
-__global__ __launch_bounds__(64 * UF_ROWS) void k_uf_verify(const float *__restrict__ wrapped_all, UfPlanes U, int h, int w, int rw)
+__global__ __launch_bounds__(1024) void k_uf_verify(const float *__restrict__ wrapped_all, UfPlanes U, int h, int w, int rw)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
     const size_t b = blockIdx.y;
     if (U.ctl[b * UFC_N + UFC_FAIL]) return;
     const size_t P = (size_t)h * w;
     bool bad = false;
     for (int r = 0; r < rw; r++) {
-    const int y = (blockIdx.x * UF_ROWS + wave) * rw + r;
+    const int y = (blockIdx.x * nwv + wave) * rw + r;
     if (y + 1 >= h) break;
     const float *w0 = wrapped_all + b * P + (size_t)y * w, *w1 = w0 + w;
     const int8_t *k0 = U.kk + b * U.P16 + (size_t)y * w, *k1 = k0 + w;
@@ -500,8 +507,9 @@ void launch_unwrap_fast(const float *wrapped, const float *quality, const uint8_
     U.ctl = (int32_t *)p;
     (void)hipMemsetAsync(U.seedkey, 0, (size_t)8 * B, st);
     // rows per wave: enough waves to fill the chip several times over, no more (a wave that lives for one row is all dispatch overhead)
-    const int rw = (long long)B * h >= 65536 ? 4 : (long long)B * h >= 16384 ? 2 : 1;
-    const dim3 rows((h + UF_ROWS * rw - 1) / (UF_ROWS * rw), B), blk(64 * UF_ROWS);
+    // (measured at 224 x 224 x 256: 4 waves x 4 rows 0.31 ms, 8 x 2 0.33, 2 x 8 0.34, 4 x 1 0.36, 16 x 1 0.41 -- the shape is not what these passes cost)
+    const int rw = (long long)B * h >= 65536 ? 4 : (long long)B * h >= 16384 ? 2 : 1, nwv = 4;
+    const dim3 rows((h + nwv * rw - 1) / (nwv * rw), B), blk(64 * nwv);
     hipLaunchKernelGGL(k_uf_count, rows, blk, 0, st, quality, mask, U, h, w, rw);
     hipLaunchKernelGGL(k_uf_scan, dim3(B), dim3(1024), 0, st, U, h);
     hipLaunchKernelGGL(k_uf_rows, rows, blk, 0, st, wrapped, mask, U, h, w, rw);
