@@ -82,6 +82,31 @@ int vistaf_temp_feature_planes(vistaf_tempseg_handle *h, const uint8_t *d_bgr, i
 int vistaf_temp_color_support(vistaf_tempseg_handle *h, const float *d_a, const float *d_b, const uint8_t *d_light, const uint8_t *d_roi_eff,
                               const uint8_t *d_sat, double chroma_min, int dilate_ksize, float *d_chroma, uint8_t *d_support, void *stream);
 
+/* Third slice (round 3): the map-domain stages behind the regressors.  PARITY UNPINNED -- the reference tree holds no output of these stages
+ * (temperature_map_*.npy were not mounted) and the regressors that feed them only exist as pickles; checked against the restatement of the
+ * source text in oracle/temp_oracle.py on synthetic planes.  Maps are float32 [H,W] with NaN = no value, masks uint8 0/1.
+ *
+ *   vistaf_temp_clamp_map       :538-543 `clamp_map(m, roi, lo, hi)`
+ *   vistaf_temp_inpaint_map     :546-580 `inpaint_temperature_map(temp_map, roi_mask, radius)`: 8-bit rescaling over the range of the known
+ *                               values, cv2.inpaint(INPAINT_TELEA) of the missing ROI pixels with OpenCV's 8-bit rounding of every estimate,
+ *                               EVERY ROI pixel read back from the 8-bit image; the two early returns (nothing missing / known; flat map) included
+ *   vistaf_temp_fuse_maps       :594-636 `fuse_maps_per_pixel(roi, wide_map, color_map)`: d_source 0 = wide, 255 = colour, 128 = blend (may be NULL);
+ *                               counts_host[4] = roi, wide_ok, color_ok, blend pixels (may be NULL; non-NULL synchronises `stream`)
+ *   vistaf_temp_oriented_blur   :705-747 `oriented_gaussian_blur_float(map, roi, angle_rad, sigma_across, sigma_along)`: warpAffine (INTER_LINEAR,
+ *                               BORDER_REFLECT; the ROI with INTER_NEAREST) by getRotationMatrix2D, anisotropic GaussianBlur, rotate back.
+ *                               Uploads the two tap vectors (synchronises `stream`). */
+typedef struct vistaf_temp_fuse_config {     /* Code/temperature_sensor.py:55-64, defaults as shipped */
+    double color_t_min, color_t_max;         /* 20, 33 */
+    double color_guard_band, switch_margin_c;/* 0.5, 1.0 */
+    double final_t_min, final_t_max;         /* 20, 75 */
+} vistaf_temp_fuse_config;
+int vistaf_temp_clamp_map(vistaf_tempseg_handle *h, const float *d_map, const uint8_t *d_roi, double lo, double hi, float *d_out, void *stream);
+int vistaf_temp_inpaint_map(vistaf_tempseg_handle *h, const float *d_map, const uint8_t *d_roi, int radius, float *d_out, void *stream);
+int vistaf_temp_fuse_maps(vistaf_tempseg_handle *h, const uint8_t *d_roi, const float *d_wide, const float *d_color, const vistaf_temp_fuse_config *cfg,
+                          float *d_final, uint8_t *d_source, int64_t *counts_host, void *stream);
+int vistaf_temp_oriented_blur(vistaf_tempseg_handle *h, const float *d_map, const uint8_t *d_roi, double angle_rad, double sigma_across, double sigma_along,
+                              float *d_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

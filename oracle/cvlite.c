@@ -93,15 +93,20 @@ void cvl_gaussian_kernel_f32(int n, double sigma, float *out)
  * rounding per tap, the more accurate of the two -- is the restatement, and the GPU kernels (k_gauss_*) execute
  * exactly this sequence, so the blurred planes agree bit for bit.
  * target_clones: the "fma" clone inlines fmaf as vfmadd*, the default clone calls libm's (same result). */
+void cvl_gaussian_blur_xy_f32(const float *src, float *dst, int h, int w, double sigmax, double sigmay);
+void cvl_gaussian_blur_f32(const float *src, float *dst, int h, int w, double sigma) { cvl_gaussian_blur_xy_f32(src, dst, h, w, sigma, sigma); }
+
+/* cv::GaussianBlur(src, (0, 0), sigmaX, sigmaY): each direction with its own kernel; sigmaY <= 0 takes sigmaX (cv::createGaussianKernels) */
 #if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__) && !defined(CVL_NO_CLONES)
 __attribute__((target_clones("fma", "default")))
 #endif
-void cvl_gaussian_blur_f32(const float *src, float *dst, int h, int w, double sigma)
+void cvl_gaussian_blur_xy_f32(const float *src, float *dst, int h, int w, double sigmax, double sigmay)
 {
-    int n = cvl_gaussian_ksize_f32(sigma);
+    if (sigmay <= 0) sigmay = sigmax;
+    int n = cvl_gaussian_ksize_f32(sigmax);
     int r = n / 2;
     float *k = (float *)malloc(sizeof(float) * (size_t)n);
-    cvl_gaussian_kernel_f32(n, sigma, k);
+    cvl_gaussian_kernel_f32(n, sigmax, k);
     float *tmp = (float *)malloc(sizeof(float) * (size_t)h * (size_t)w);
     int *xi = (int *)malloc(sizeof(int) * (size_t)(w + 2 * r));
     for (int x = -r; x < w + r; x++) xi[x + r] = reflect101(x, w);
@@ -114,6 +119,11 @@ void cvl_gaussian_blur_f32(const float *src, float *dst, int h, int w, double si
             t[x] = acc;
         }
     }
+    free(k);
+    n = cvl_gaussian_ksize_f32(sigmay);
+    r = n / 2;
+    k = (float *)malloc(sizeof(float) * (size_t)n);
+    cvl_gaussian_kernel_f32(n, sigmay, k);
     int *yi = (int *)malloc(sizeof(int) * (size_t)(h + 2 * r));
     for (int y = -r; y < h + r; y++) yi[y + r] = reflect101(y, h);
     for (int y = 0; y < h; y++) {
@@ -400,6 +410,7 @@ static float min4f(float a, float b, float c, float d)
 { a = a < b ? a : b; c = c < d ? c : d; return a < c ? a : c; }
 
 /* optional log of the march's fill sequence (diagnostics and the test of the GPU's ordering pass): fill number per pixel, -1 = not filled */
+static int g_round_u8 = 0;             /* 8-bit variant: the estimate gets + 0.5f, cvRound and saturate_cast<uchar> (values stay floats holding 0..255) */
 static int32_t *g_fill_index = NULL;
 static int32_t g_fill_count = 0;
 /* optional log of both FMM passes' pops: rows (pass, i, j) in padded coordinates and the popped T */
@@ -560,6 +571,11 @@ void cvl_inpaint_telea_f32(const float *src, const uint8_t *inpaint_mask, float 
                     }
                 }
             }
+            if (g_round_u8) {
+                float sat = (float)((double)(Ia / s) + (double)(Jx + Jy) / (sqrt((double)(Jx * Jx + Jy * Jy)) + (double)1.0e-20f) + (double)0.5f);
+                long isat = lrint((double)sat);
+                OO(i - 1, j - 1) = (float)(isat < 0 ? 0 : isat > 255 ? 255 : isat);
+            } else
             OO(i - 1, j - 1) = (float)((double)(Ia / s) + (double)(Jx + Jy) / (sqrt((double)(Jx * Jx + Jy * Jy)) + (double)1.0e-20f));
 #undef FF
 #undef TT
@@ -570,6 +586,15 @@ void cvl_inpaint_telea_f32(const float *src, const uint8_t *inpaint_mask, float 
         }
     }
     free(heap.e); free(outq.e); free(t); free(mask); free(band); free(out);
+}
+
+/* cv::inpaint on an 8-bit single-channel image (photo/inpaint.cpp, the uchar branch of icvTeleaInpaintFMM): src / dst hold the 0..255 values
+ * as floats; every estimate is rounded as OpenCV rounds it (+ 0.5f, cvRound, saturate).  Not pinned by any file of the reference. */
+void cvl_inpaint_telea_u8_f32(const float *src, const uint8_t *inpaint_mask, float *dst, int h, int w, double radius)
+{
+    g_round_u8 = 1;
+    cvl_inpaint_telea_f32(src, inpaint_mask, dst, h, w, radius);
+    g_round_u8 = 0;
 }
 
 /* the same call, also logging every pop of the outside pass (pass 0) and of the march (pass 1): returns the number of pops */

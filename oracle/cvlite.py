@@ -156,6 +156,26 @@ def inpaint_telea(src, mask, radius: float) -> np.ndarray:
     return dst
 
 
+def inpaint_telea_u8(src_u8, mask, radius: float) -> np.ndarray:
+    """cv2.inpaint(src_u8, mask_u8, radius, cv2.INPAINT_TELEA) on an 8-bit single-channel image (parity unpinned: no file of the reference holds
+    an output of this call)."""
+    src = _f32(np.asarray(src_u8, np.uint8))
+    m = _u8(mask)
+    dst = np.empty_like(src)
+    h, w = src.shape
+    lib().cvl_inpaint_telea_u8_f32(_p(src), _p(m), _p(dst), ctypes.c_int(h), ctypes.c_int(w), ctypes.c_double(radius))
+    return dst.astype(np.uint8)
+
+
+def gaussian_blur_xy(src, sigma_x: float, sigma_y: float) -> np.ndarray:
+    """cv2.GaussianBlur(src_f32, (0, 0), sigmaX=sigma_x, sigmaY=sigma_y) -- BORDER_REFLECT_101."""
+    src = _f32(src)
+    dst = np.empty_like(src)
+    h, w = src.shape
+    lib().cvl_gaussian_blur_xy_f32(_p(src), _p(dst), ctypes.c_int(h), ctypes.c_int(w), ctypes.c_double(sigma_x), ctypes.c_double(sigma_y))
+    return dst
+
+
 def inpaint_telea_order(src, mask, radius: float):
     """inpaint_telea plus the march's fill sequence: (dst, fill_index int32 [h, w], -1 where nothing was filled)."""
     src = _f32(src)

@@ -30,6 +30,8 @@ from __future__ import annotations
 import dataclasses
 from typing import Any, Dict, Tuple
 
+import math
+
 import numpy as np
 
 from . import align_oracle as A
@@ -281,3 +283,107 @@ def color_support_mask(planes: Dict[str, np.ndarray], light_mask: np.ndarray, ro
     chroma = np.sqrt((a - 128.0) ** 2 + (b - 128.0) ** 2).astype(np.float32)
     light_d = dilate_bool_mask(light_mask, cfg.color_support_dilate)
     return light_d & roi_eff & (~sat) & (chroma >= float(cfg.color_chroma_min)), chroma
+
+
+# ---------------------------------------------------------------------------------------------
+# Map utilities, fusion, final smoothing: Code/temperature_sensor.py:538-640, :705-747.
+# PARITY UNPINNED: the reference tree holds no output of these stages (temperature_map_*.npy are in .MISSING_LARGE_BLOBS) and the
+# regressors that feed them only exist as pickles; these restatements follow the source text and OpenCV's documented semantics.
+# ---------------------------------------------------------------------------------------------
+COLOR_T_MIN, COLOR_T_MAX = 20.0, 33.0            # :55-56
+COLOR_GUARD_BAND, SWITCH_MARGIN_C = 0.5, 1.0     # :59-60
+FINAL_T_MIN, FINAL_T_MAX = 20.0, 75.0            # :63-64
+FINAL_SMOOTH_SIGMA_ACROSS, FINAL_SMOOTH_SIGMA_ALONG = 6.0, 1.0      # :95-96
+
+
+def clamp_map(m: np.ndarray, roi: np.ndarray, lo: float, hi: float) -> np.ndarray:
+    """:538-543"""
+    out = m.copy()
+    sel = roi & np.isfinite(out)
+    out[sel] = np.clip(out[sel], float(lo), float(hi))
+    out[~roi] = np.nan
+    return out
+
+
+def inpaint_temperature_map(temp_map: np.ndarray, roi_mask: np.ndarray, radius: int = 7) -> np.ndarray:
+    """:546-580: the map is scaled to 8 bits over the range of its known values, cv2.inpaint (Telea) fills the missing pixels of the ROI, and
+    EVERY pixel of the ROI is read back from the 8-bit image (the known ones are quantised to 1/255 of the range, as upstream)."""
+    out = temp_map.copy()
+    inside = roi_mask
+    known = inside & np.isfinite(out)
+    missing = inside & (~np.isfinite(out))
+    if not np.any(missing) or not np.any(known):
+        out[~inside] = np.nan
+        return out
+    vals = out[known]
+    vmin = float(np.nanmin(vals))
+    vmax = float(np.nanmax(vals))
+    if vmax - vmin < 1e-6:
+        out[missing] = vmin
+        out[~inside] = np.nan
+        return out
+    scaled = np.zeros_like(out, dtype=np.uint8)
+    scaled[known] = ((out[known] - vmin) / (vmax - vmin) * 255.0).clip(0, 255).astype(np.uint8)
+    filled = cv.inpaint_telea_u8(scaled, missing.astype(np.uint8) * 255, float(int(radius)))
+    out_filled = out.copy()
+    out_filled[inside] = (filled[inside].astype(np.float32) / 255.0) * (vmax - vmin) + vmin
+    out_filled[~inside] = np.nan
+    return out_filled
+
+
+def fuse_maps_per_pixel(roi: np.ndarray, wide_map: np.ndarray, color_map: np.ndarray):
+    """:594-636"""
+    final = wide_map.copy()
+    source = np.zeros(final.shape, dtype=np.uint8)
+    wide_ok = roi & np.isfinite(wide_map)
+    with np.errstate(invalid="ignore"):
+        color_ok = roi & np.isfinite(color_map) & (color_map >= (COLOR_T_MIN - COLOR_GUARD_BAND)) & (color_map <= (COLOR_T_MAX + COLOR_GUARD_BAND))
+        final[color_ok] = color_map[color_ok]
+        source[color_ok] = 255
+        low_th = COLOR_T_MAX - SWITCH_MARGIN_C
+        high_th = COLOR_T_MAX + SWITCH_MARGIN_C
+        blend_zone = wide_ok & color_ok & (wide_map > low_th) & (wide_map < high_th)
+    if np.any(blend_zone):
+        w = (high_th - wide_map[blend_zone]) / (high_th - low_th)
+        w = np.clip(w, 0.0, 1.0).astype(np.float32)
+        final[blend_zone] = w * color_map[blend_zone] + (1.0 - w) * wide_map[blend_zone]
+        source[blend_zone] = 128
+    final = clamp_map(final, roi, FINAL_T_MIN, FINAL_T_MAX)
+    dbg = {"roi_pixels": int(np.count_nonzero(roi)), "wide_ok_pixels": int(np.count_nonzero(wide_ok)),
+           "color_ok_pixels": int(np.count_nonzero(color_ok)), "blend_pixels": int(np.count_nonzero(blend_zone))}
+    return final.astype(np.float32), source, dbg
+
+
+def rotation_matrix_2d(center, angle_deg: float, scale: float = 1.0) -> np.ndarray:
+    """cv::getRotationMatrix2D (double)."""
+    a = math.radians(float(angle_deg))
+    al, be = scale * math.cos(a), scale * math.sin(a)
+    cx, cy = float(center[0]), float(center[1])
+    return np.array([[al, be, (1 - al) * cx - be * cy], [-be, al, be * cx + (1 - al) * cy]], np.float64)
+
+
+def oriented_gaussian_blur_float(map_f: np.ndarray, roi: np.ndarray, angle_rad: float, sigma_across: float, sigma_along: float) -> np.ndarray:
+    """:705-747: rotate so that "across the stripes" is +x (warpAffine INTER_LINEAR, BORDER_REFLECT; the ROI with INTER_NEAREST, constant 0),
+    anisotropic GaussianBlur, rotate back, NaN outside the twice-rotated ROI."""
+    from . import align_oracle as A
+    if sigma_across <= 0 and sigma_along <= 0:
+        out = map_f.copy()
+        out[~roi] = np.nan
+        return out
+    h, w = map_f.shape
+    center = (w / 2.0, h / 2.0)
+    angle_deg = -float(angle_rad) * 180.0 / float(np.pi)
+    map0 = map_f.copy()
+    map0[~np.isfinite(map0)] = 0.0
+    roi_u8 = roi.astype(np.uint8) * 255
+    M = rotation_matrix_2d(center, angle_deg)
+    rot_map = A.warp_affine(map0.astype(np.float32), M, False, border="reflect")
+    rot_roi = A.warp_affine(roi_u8, M, False, nearest=True) > 127
+    sx, sy = float(max(0.0, sigma_across)), float(max(0.0, sigma_along))
+    blurred = cv.gaussian_blur_xy(rot_map.astype(np.float32), sx, sy)
+    M_inv = rotation_matrix_2d(center, -angle_deg)
+    back = A.warp_affine(blurred, M_inv, False, border="reflect")
+    back_roi = A.warp_affine(rot_roi.astype(np.uint8) * 255, M_inv, False, nearest=True) > 127
+    out = back.astype(np.float32)
+    out[~back_roi] = np.nan
+    return out

@@ -185,3 +185,75 @@ def test_gpu_feature_planes_match_oracle_on_partial_tiles(pkg, h, w, blur, seed)
     with pytest.raises(ValueError):
         seg.feature_planes(img, 7)
     seg.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# Third slice (round 3): map-domain stages behind the regressors -- PARITY UNPINNED (no output of these stages is in the reference tree);
+# the HIP kernels against oracle/temp_oracle.py's restatement of Code/temperature_sensor.py:538-640, :705-747 on synthetic planes.
+# ------------------------------------------------------------------------------------------------------------------------------------
+def _synthetic_maps(h, w, seed):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    roi = ((yy - h / 2) ** 2 + (xx - w / 2) ** 2) < (0.42 * min(h, w)) ** 2
+    wide = (34.0 + 22.0 * np.sin(xx / 17.0) * np.cos(yy / 23.0) + 3.0 * rng.standard_normal((h, w))).astype(np.float32)
+    wide[rng.random((h, w)) < 0.04] = np.nan                                     # scattered holes of the wide model
+    wide[int(0.3 * h):int(0.3 * h) + 6, int(0.4 * w):int(0.4 * w) + 9] = np.nan   # and a block
+    support = roi & (((yy - 0.55 * h) ** 2 + (xx - 0.45 * w) ** 2) < (0.25 * min(h, w)) ** 2)
+    color = (27.0 + 8.0 * np.cos(yy / 13.0) + 0.5 * rng.standard_normal((h, w))).astype(np.float32)
+    color[~support] = np.nan
+    color[support & (rng.random((h, w)) < 0.05)] = np.nan
+    return roi, wide, support, color
+
+
+def test_oracle_map_stages_known_answers():
+    """CPU: properties of the restated map stages that follow from the source text (clamp: NaN outside the ROI, clipped inside; inpaint: every
+    ROI pixel finite and quantised to 1/255 of the known range; fusion: the three source codes and their counts; smoothing with both sigmas 0
+    is the identity inside the ROI)."""
+    roi, wide, support, color = _synthetic_maps(96, 128, 5)
+    c = T.clamp_map(wide, roi, 25.0, 40.0)
+    assert np.isnan(c[~roi]).all() and np.nanmin(c[roi]) >= 25.0 and np.nanmax(c[roi]) <= 40.0
+    assert np.array_equal(np.isnan(c[roi]), np.isnan(wide[roi]))
+    wi = T.inpaint_temperature_map(wide, roi, 7)
+    assert np.isfinite(wi[roi]).all() and np.isnan(wi[~roi]).all()
+    known = roi & np.isfinite(wide)
+    vmin, vmax = float(wide[known].min()), float(wide[known].max())
+    q = (wi[roi] - vmin) / (vmax - vmin) * 255.0
+    assert np.abs(q - np.rint(q)).max() < 1e-3                                    # read back from the 8-bit image
+    assert np.abs(wi[known] - wide[known]).max() <= (vmax - vmin) / 255.0 + 1e-4
+    f, src, dbg = T.fuse_maps_per_pixel(roi, T.clamp_map(wi, roi, T.FINAL_T_MIN, T.FINAL_T_MAX), color)
+    assert set(np.unique(src)) <= {0, 128, 255} and dbg["blend_pixels"] == int((src == 128).sum()) and dbg["blend_pixels"] > 0
+    assert dbg["color_ok_pixels"] == int((src >= 128).sum())
+    ident = T.oriented_gaussian_blur_float(f, roi, 0.3, 0.0, 0.0)
+    assert np.array_equal(ident[roi], f[roi]) and np.isnan(ident[~roi]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,seed", [(96, 128, 1), (160, 203, 2), (240, 320, 3)])
+def test_gpu_map_stages_match_oracle(pkg, h, w, seed):
+    """HIP clamp / inpaint / fusion / oriented smoothing against the oracle restatement, stage by stage on the oracle's own inputs and as a chain.
+    Elementwise stages and the inpaint (integer-valued 8-bit march, same pop order and estimator arithmetic) must agree exactly; the smoothing
+    goes through two bilinear warps and a float Gaussian and is compared at 1e-5 relative."""
+    roi, wide, support, color = _synthetic_maps(h, w, seed)
+    seg = pkg.tempseg.TempSegmenter(h, w)
+    # clamp_map
+    assert np.array_equal(seg.clamp_map(wide, roi, 25.0, 40.0), T.clamp_map(wide, roi, 25.0, 40.0), equal_nan=True)
+    # inpaint_temperature_map, both radii of main() (:835-840), and its early returns
+    for m, r, rad in ((wide, roi, 7), (color, support, 5)):
+        assert np.array_equal(seg.inpaint_temperature_map(m, r, rad), T.inpaint_temperature_map(m, r, rad), equal_nan=True), rad
+    full = np.where(np.isfinite(wide), wide, np.float32(30.0)).astype(np.float32)
+    assert np.array_equal(seg.inpaint_temperature_map(full, roi, 7), T.inpaint_temperature_map(full, roi, 7), equal_nan=True)      # nothing missing
+    flat = np.where(np.isfinite(wide), np.float32(31.5), np.float32(np.nan)).astype(np.float32)
+    assert np.array_equal(seg.inpaint_temperature_map(flat, roi, 7), T.inpaint_temperature_map(flat, roi, 7), equal_nan=True)      # flat map
+    # the chain of main() :835-855
+    wide_o = T.clamp_map(T.inpaint_temperature_map(wide, roi, 7), roi, T.FINAL_T_MIN, T.FINAL_T_MAX)
+    color_o = T.clamp_map(T.inpaint_temperature_map(color, support, 5), support, T.COLOR_T_MIN - 5.0, T.COLOR_T_MAX + 5.0)
+    f_o, src_o, dbg_o = T.fuse_maps_per_pixel(roi, wide_o, color_o)
+    f_g, src_g, dbg_g = seg.fuse_maps_per_pixel(roi, wide_o, color_o)
+    assert np.array_equal(f_g, f_o, equal_nan=True) and np.array_equal(src_g, src_o) and dbg_g == dbg_o
+    for angle in (0.0, 0.31, -1.2):
+        o = T.oriented_gaussian_blur_float(f_o, roi, angle, T.FINAL_SMOOTH_SIGMA_ACROSS, T.FINAL_SMOOTH_SIGMA_ALONG)
+        g = seg.oriented_gaussian_blur_float(f_o, roi, angle, T.FINAL_SMOOTH_SIGMA_ACROSS, T.FINAL_SMOOTH_SIGMA_ALONG)
+        assert np.array_equal(np.isnan(g), np.isnan(o)), angle
+        fin = np.isfinite(o)
+        assert np.abs(g[fin] - o[fin]).max() <= 1e-5 * np.abs(o[fin]).max(), angle
+    seg.close()

@@ -28,7 +28,8 @@ EXPORTS = [
 ]
 TEST_EXPORTS = ["vistaf_ftp_test_set"]   # csrc/test_hooks.h: kernel tier selection / debug planes for the parity tests
 TEMP_EXPORTS = ["vistaf_tempseg_default_config", "vistaf_tempseg_create", "vistaf_tempseg_destroy", "vistaf_tempseg_segment",
-                "vistaf_temp_feature_planes", "vistaf_temp_color_support"]   # include/vistaf_temp.h
+                "vistaf_temp_feature_planes", "vistaf_temp_color_support",
+                "vistaf_temp_clamp_map", "vistaf_temp_inpaint_map", "vistaf_temp_fuse_maps", "vistaf_temp_oriented_blur"]   # include/vistaf_temp.h
 TEMPSEG_NINFO = 16
 ALIGN_EXPORTS = [            # include/vistaf_align.h
     "vistaf_align_default_config", "vistaf_align_create", "vistaf_align_destroy", "vistaf_align_geometry",
@@ -57,6 +58,10 @@ _DBL_FIELDS = [
 
 class CConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in _INT_FIELDS] + [(n, ctypes.c_double) for n in _DBL_FIELDS]
+
+
+class CTempFuseConfig(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_double) for n in ("color_t_min", "color_t_max", "color_guard_band", "switch_margin_c", "final_t_min", "final_t_max")]
 
 
 class CTempSegConfig(ctypes.Structure):
@@ -108,6 +113,10 @@ def load():
     lib.vistaf_tempseg_segment.argtypes = [vp, vp, vp, vp, vp, vp, vp, ctypes.POINTER(cd), vp]
     lib.vistaf_temp_feature_planes.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp]
     lib.vistaf_temp_color_support.argtypes = [vp, vp, vp, vp, vp, vp, cd, ci, vp, vp, vp]
+    lib.vistaf_temp_clamp_map.argtypes = [vp, vp, vp, cd, cd, vp, vp]
+    lib.vistaf_temp_inpaint_map.argtypes = [vp, vp, vp, ci, vp, vp]
+    lib.vistaf_temp_fuse_maps.argtypes = [vp, vp, vp, vp, ctypes.POINTER(CTempFuseConfig), vp, vp, ctypes.POINTER(ctypes.c_int64), vp]
+    lib.vistaf_temp_oriented_blur.argtypes = [vp, vp, vp, cd, cd, cd, vp, vp]
     for fn in EXPORTS + ALIGN_EXPORTS + TEST_EXPORTS + TEMP_EXPORTS:
         getattr(lib, fn)
     _lib = lib

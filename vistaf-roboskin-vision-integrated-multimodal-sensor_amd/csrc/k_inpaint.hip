@@ -181,7 +181,7 @@ struct TeleaScan { int i0, i1, j0, j1; const int32_t *lab; int root; };
 
 template <bool LF>
 __device__ __attribute__((always_inline)) inline void telea_march_global(float *img, int range, uint8_t *f, uint8_t *fo, float *t, TQueue &q,
-                                                                         const TeleaScan sc, int h, int w, int lane, size_t b)
+                                                                         const TeleaScan sc, int h, int w, int lane, size_t b, bool round_u8 = false)
 {
     const int er = h + 2, ec = w + 2;
     // raster scan of the window, 64 columns at a time: the cells of this march that satisfy `pred`
@@ -358,7 +358,7 @@ __device__ __attribute__((always_inline)) inline void telea_march_global(float *
                     sJy = wn_seq_sum_n(-cJy, sJy, nl, lane);
                     sS = wn_seq_sum_n(cS, sS, nl, lane);
                 }
-                float val = telea_estimate(sIa, sJx, sJy, sS);
+                const float val = round_u8 ? telea_estimate_u8(sIa, sJx, sJy, sS) : telea_estimate(sIa, sJx, sJy, sS);
                 if (lane == 0) { img[(size_t)(i - 1) * w + (j - 1)] = val; f[pi] = T_BAND; }
                 tq_push<LF>(q, dist, pi, lane);
                 if (LF) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -375,7 +375,7 @@ __device__ __attribute__((always_inline)) inline void telea_march_global(float *
 template <bool LF>
 __global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const uint8_t *__restrict__ bad_all, int range,
                                               uint8_t *gflags, float *gT, uint32_t *gqueue, const int32_t *__restrict__ nbad_all, int32_t *status, int h,
-                                              int w)
+                                              int w, int round_u8)
 {
     extern __shared__ unsigned char lds_raw[];
     const int lane = threadIdx.x;
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const
         __syncthreads();
     }
     const TeleaScan sc = {0, er - 1, 0, ec - 1, nullptr, 0};
-    telea_march_global<LF>(img, range, f, fo, t, q, sc, h, w, lane, b);
+    telea_march_global<LF>(img, range, f, fo, t, q, sc, h, w, lane, b, round_u8 != 0);
     if (q.overflow && lane == 0) status[b] = 2;
     (void)bad_all;
 }
@@ -460,7 +460,7 @@ static size_t telea_lds_bytes(int h, int w)
 }
 
 void launch_inpaint_telea(float *img, const uint8_t *bad, int range, void *scratch, int32_t *status, const int32_t *only, int B, int h,
-                          int w, hipStream_t st)
+                          int w, hipStream_t st, bool round_u8)
 {
     size_t en = (size_t)(h + 2) * (w + 2);
     // scratch layout: [B*en floats T][B*2*en bytes flags]
@@ -474,9 +474,9 @@ void launch_inpaint_telea(float *img, const uint8_t *bad, int range, void *scrat
     if (lds_full <= 160 * 1024) {
         static DynLdsOnce lds_once;
         ensure_dyn_lds(lds_once, (const void *)k_telea<true>, 160 * 1024);
-        hipLaunchKernelGGL(k_telea<true>, dim3(B), dim3(64), lds_full, st, img, bad, range, gflags, gT, gqueue, nbad, status, h, w);
+        hipLaunchKernelGGL(k_telea<true>, dim3(B), dim3(64), lds_full, st, img, bad, range, gflags, gT, gqueue, nbad, status, h, w, round_u8 ? 1 : 0);
     } else {
-        hipLaunchKernelGGL(k_telea<false>, dim3(B), dim3(64), 0, st, img, bad, range, gflags, gT, gqueue, nbad, status, h, w);
+        hipLaunchKernelGGL(k_telea<false>, dim3(B), dim3(64), 0, st, img, bad, range, gflags, gT, gqueue, nbad, status, h, w, round_u8 ? 1 : 0);
     }
 }
 

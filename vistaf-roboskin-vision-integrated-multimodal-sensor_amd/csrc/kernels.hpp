@@ -94,7 +94,7 @@ void launch_erode_by_dist(const float *dist, const uint8_t *src, float margin, u
 size_t inpaint_scratch_bytes_per_frame(int h, int w);
 // `only` (device, [B], may be null): process just the frames with only[b] != 0
 void launch_inpaint_telea(float *img, const uint8_t *bad, int range, void *scratch, int32_t *status, const int32_t *only, int B, int h, int w,
-                          hipStream_t st);
+                          hipStream_t st, bool round_u8 = false);      // round_u8: 8-bit image semantics (values 0..255 held as floats, OpenCV's rounding of every estimate)
 
 // ---- k_inpaint_win.hip (LDS-resident window kernel; returns the per-frame fallback flags for launch_inpaint_telea)
 size_t inpaint_win_scratch_bytes(int B);
@@ -173,5 +173,19 @@ void launch_fill_scalars(double *scalars, int nscal, const int *rel_count, const
 void launch_mark_empty(const int *rel_count, int32_t *status, int B, hipStream_t st);
 void launch_copy_out(const float *depth, const uint8_t *reliable, const int32_t *status, float *out_h, uint8_t *out_r, int B, int P,
                      hipStream_t st);
+
+// ---- k_tempmap.hip (map-domain stages of the temperature modality; parity unpinned, see the file)
+struct TmAff { double m[6]; };          // source = M * (x, y, 1): the inverse map cv::warpAffine iterates with
+struct TmFuse { float color_lo, color_hi, low_th, high_th, final_lo, final_hi; };
+void launch_tm_clamp(const float *m, const uint8_t *roi, float lo, float hi, float *out, size_t P, hipStream_t st);
+void launch_tm_stats(const float *m, const uint8_t *roi, uint32_t *stats, size_t P, hipStream_t st);
+void launch_tm_scale(const float *m, const uint8_t *roi, const uint32_t *stats, float *scaled, uint8_t *miss, size_t P, hipStream_t st);
+void launch_tm_unscale(const float *m, const uint8_t *roi, const uint32_t *stats, const float *filled, float *out, size_t P, hipStream_t st);
+void launch_tm_fuse(const uint8_t *roi, const float *wide, const float *color, const TmFuse &c, float *fin, uint8_t *source, unsigned long long *counts, size_t P,
+                    hipStream_t st);
+void launch_tm_zero_nonfinite(const float *m, float *out, size_t P, hipStream_t st);
+void launch_tm_warp_linear(const float *src, float *dst, const TmAff &a, int h, int w, hipStream_t st);
+void launch_tm_warp_nearest(const uint8_t *src, uint8_t *dst, const TmAff &a, int h, int w, hipStream_t st);
+void launch_tm_mask_nan(const float *m, const uint8_t *keep, float *out, size_t P, hipStream_t st);
 
 }  // namespace vf

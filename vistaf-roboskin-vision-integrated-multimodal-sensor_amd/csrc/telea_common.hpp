@@ -63,10 +63,16 @@ __device__ inline float wn_seq_sum_n(float x, float init, int n, int lane)
 }
 // Ia / s + (Jx + Jy) / (sqrt(Jx^2 + Jy^2) + 1e-20): the float quotient and sums promoted to double for the second term and the final
 // addition (inpaint.cpp's expression with its double-precision sqrt)
-__device__ inline float telea_estimate(float Ia, float Jx, float Jy, float s)
+__device__ inline double telea_estimate_d(float Ia, float Jx, float Jy, float s)
 {
-    return (float)((double)__fdiv_rn(Ia, s) +
-                   (double)__fadd_rn(Jx, Jy) / (sqrt((double)__fadd_rn(__fmul_rn(Jx, Jx), __fmul_rn(Jy, Jy))) + (double)1.0e-20f));
+    return (double)__fdiv_rn(Ia, s) + (double)__fadd_rn(Jx, Jy) / (sqrt((double)__fadd_rn(__fmul_rn(Jx, Jx), __fmul_rn(Jy, Jy))) + (double)1.0e-20f);
+}
+__device__ inline float telea_estimate(float Ia, float Jx, float Jy, float s) { return (float)telea_estimate_d(Ia, Jx, Jy, s); }
+// the uchar branch of icvTeleaInpaintFMM (8-bit images, here as floats holding 0..255): + 0.5f, cvRound, saturate_cast<uchar>
+__device__ inline float telea_estimate_u8(float Ia, float Jx, float Jy, float s)
+{
+    const float sat = (float)(telea_estimate_d(Ia, Jx, Jy, s) + (double)0.5f);
+    return fminf(fmaxf(rintf(sat), 0.f), 255.f);
 }
 // 1 / (1 + |T - Tc|) formed in double and rounded to float (inpaint.cpp: lev = (float)(1./(1+fabs(...))))
 __device__ inline float telea_lev(float tk, float tc) { return (float)(1.0 / (1.0 + (double)fabsf(__fsub_rn(tk, tc)))); }

@@ -179,6 +179,13 @@ struct vistaf_tempseg_handle {
     hipfftHandle plan = 0;
     bool have_plan = false;
     uint16_t *gamma_tab = nullptr, *cbrt_tab = nullptr;       // cv::RGB2Lab_b tables
+    // map-domain stages (allocated on first use): two float planes, two masks, the whole-frame march's scratch, counters, Gaussian taps
+    float *tmA = nullptr, *tmB = nullptr, *tm_kx = nullptr, *tm_ky = nullptr;
+    uint8_t *tmM1 = nullptr, *tmM2 = nullptr;
+    void *tm_scratch = nullptr;
+    uint32_t *tm_stats = nullptr;
+    int32_t *tm_status = nullptr;
+    unsigned long long *tm_counts = nullptr;
     LabCoef lab;
 };
 
@@ -413,6 +420,135 @@ int vistaf_temp_color_support(vistaf_tempseg_handle *h, const float *d_a, const 
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(VISTAF_E_HIP, std::string("launch: ") + hipGetErrorString(e));
     return 0;
+}
+
+// ---- map-domain stages (Code/temperature_sensor.py:538-640, :705-747); parity unpinned (k_tempmap.hip)
+static int tm_ensure(vistaf_tempseg_handle *h)
+{
+    if (h->tmA) return 0;
+    int rc = 0;
+#define TMTRY(x) do { rc = (x); if (rc) return rc; } while (0)
+    TMTRY(talloc(h, &h->tmA, h->P)); TMTRY(talloc(h, &h->tmB, h->P));
+    TMTRY(talloc(h, &h->tmM1, h->P)); TMTRY(talloc(h, &h->tmM2, h->P));
+    TMTRY(talloc(h, &h->tm_kx, (size_t)1024)); TMTRY(talloc(h, &h->tm_ky, (size_t)1024));
+    uint8_t *p = nullptr;
+    TMTRY(talloc(h, &p, inpaint_scratch_bytes_per_frame(h->H, h->W))); h->tm_scratch = p;
+    TMTRY(talloc(h, &h->tm_stats, (size_t)4)); TMTRY(talloc(h, &h->tm_status, (size_t)4)); TMTRY(talloc(h, &h->tm_counts, (size_t)4));
+#undef TMTRY
+    return 0;
+}
+static int tm_done(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(VISTAF_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    return 0;
+}
+
+int vistaf_temp_clamp_map(vistaf_tempseg_handle *h, const float *d_map, const uint8_t *d_roi, double lo, double hi, float *d_out, void *stream)
+{
+    if (!h || !d_map || !d_roi || !d_out) return set_error(VISTAF_E_INVALID, "null argument");
+    launch_tm_clamp(d_map, d_roi, (float)lo, (float)hi, d_out, h->P, (hipStream_t)stream);
+    return tm_done("clamp_map");
+}
+
+int vistaf_temp_inpaint_map(vistaf_tempseg_handle *h, const float *d_map, const uint8_t *d_roi, int radius, float *d_out, void *stream)
+{
+    if (!h || !d_map || !d_roi || !d_out) return set_error(VISTAF_E_INVALID, "null argument");
+    if (radius < 1 || radius > 100) return set_error(VISTAF_E_INVALID, "inpaint radius out of range");
+    int rc = tm_ensure(h);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    launch_tm_stats(d_map, d_roi, h->tm_stats, h->P, st);
+    launch_tm_scale(d_map, d_roi, h->tm_stats, h->tmA, h->tmM1, h->P, st);
+    (void)hipMemsetAsync(h->tm_status, 0, sizeof(int32_t), st);
+    launch_inpaint_telea(h->tmA, h->tmM1, radius, h->tm_scratch, h->tm_status, nullptr, 1, h->H, h->W, st, true);
+    launch_tm_unscale(d_map, d_roi, h->tm_stats, h->tmA, d_out, h->P, st);
+    return tm_done("inpaint_temperature_map");
+}
+
+int vistaf_temp_fuse_maps(vistaf_tempseg_handle *h, const uint8_t *d_roi, const float *d_wide, const float *d_color, const vistaf_temp_fuse_config *cfg,
+                          float *d_final, uint8_t *d_source, int64_t *counts_host, void *stream)
+{
+    if (!h || !d_roi || !d_wide || !d_color || !d_final || !cfg) return set_error(VISTAF_E_INVALID, "null argument");
+    int rc = tm_ensure(h);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    TmFuse c;
+    c.color_lo = (float)(cfg->color_t_min - cfg->color_guard_band); c.color_hi = (float)(cfg->color_t_max + cfg->color_guard_band);
+    c.low_th = (float)(cfg->color_t_max - cfg->switch_margin_c); c.high_th = (float)(cfg->color_t_max + cfg->switch_margin_c);
+    c.final_lo = (float)cfg->final_t_min; c.final_hi = (float)cfg->final_t_max;
+    launch_tm_fuse(d_roi, d_wide, d_color, c, d_final, d_source, counts_host ? h->tm_counts : nullptr, h->P, st);
+    if (counts_host) {
+        unsigned long long hc[4];
+        if (hipMemcpyAsync(hc, h->tm_counts, sizeof(hc), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+            return set_error(VISTAF_E_HIP, "fuse_maps: counters");
+        for (int i = 0; i < 4; i++) counts_host[i] = (int64_t)hc[i];
+    }
+    return tm_done("fuse_maps_per_pixel");
+}
+
+static void tm_rotation(double cx, double cy, double angle_deg, double *M)      // cv::getRotationMatrix2D, scale 1
+{
+    const double a = angle_deg * 3.14159265358979323846 / 180.0, al = std::cos(a), be = std::sin(a);
+    M[0] = al; M[1] = be; M[2] = (1 - al) * cx - be * cy;
+    M[3] = -be; M[4] = al; M[5] = be * cx + (1 - al) * cy;
+}
+static TmAff tm_invert(const double *m)                                          // cv::invertAffineTransform
+{
+    double D = m[0] * m[4] - m[1] * m[3];
+    D = D != 0 ? 1.0 / D : 0.0;
+    const double A11 = m[4] * D, A22 = m[0] * D, A12 = -m[1] * D, A21 = -m[3] * D;
+    TmAff a;
+    a.m[0] = A11; a.m[1] = A12; a.m[2] = -A11 * m[2] - A12 * m[5];
+    a.m[3] = A21; a.m[4] = A22; a.m[5] = -A21 * m[2] - A22 * m[5];
+    return a;
+}
+static int tm_taps(double sigma, float *d_k, int &n, hipStream_t st)             // cv::getGaussianKernel(ksize(sigma), sigma, CV_32F)
+{
+    n = ((int)std::nearbyint(sigma * 4 * 2 + 1)) | 1;
+    if (n > 1023) return set_error(VISTAF_E_INVALID, "smoothing sigma too large");
+    std::vector<double> t(n);
+    const double s2 = -0.5 / (sigma * sigma);
+    double sum = 0;
+    for (int i = 0; i < n; i++) { const double x = i - (n - 1) * 0.5; t[i] = std::exp(s2 * x * x); sum += t[i]; }
+    std::vector<float> f(n);
+    for (int i = 0; i < n; i++) f[i] = (float)(t[i] * (1.0 / sum));
+    if (hipMemcpyAsync(d_k, f.data(), n * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return set_error(VISTAF_E_HIP, "oriented blur: taps");
+    return 0;
+}
+
+int vistaf_temp_oriented_blur(vistaf_tempseg_handle *h, const float *d_map, const uint8_t *d_roi, double angle_rad, double sigma_across, double sigma_along,
+                              float *d_out, void *stream)
+{
+    if (!h || !d_map || !d_roi || !d_out) return set_error(VISTAF_E_INVALID, "null argument");
+    int rc = tm_ensure(h);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t P = h->P;
+    if (sigma_across <= 0 && sigma_along <= 0) {              // :713-716
+        launch_tm_mask_nan(d_map, d_roi, d_out, P, st);
+        return tm_done("oriented blur");
+    }
+    const double cx = h->W / 2.0, cy = h->H / 2.0, angle_deg = -angle_rad * 180.0 / 3.14159265358979323846;
+    double M[6], Mi[6];
+    tm_rotation(cx, cy, angle_deg, M);
+    tm_rotation(cx, cy, -angle_deg, Mi);
+    const TmAff a = tm_invert(M), ai = tm_invert(Mi);
+    double sx = sigma_across > 0 ? sigma_across : 0.0, sy = sigma_along > 0 ? sigma_along : 0.0;
+    if (sx <= 0) return set_error(VISTAF_E_INVALID, "sigma_across must be positive when sigma_along is (cv::GaussianBlur needs sigmaX > 0 for ksize (0, 0))");
+    if (sy <= 0) sy = sx;                                     // cv::createGaussianKernels: sigmaY <= 0 takes sigmaX
+    int nx = 0, ny = 0;
+    if ((rc = tm_taps(sx, h->tm_kx, nx, st)) || (rc = tm_taps(sy, h->tm_ky, ny, st))) return rc;
+    launch_tm_zero_nonfinite(d_map, h->tmA, P, st);
+    launch_tm_warp_linear(h->tmA, h->tmB, a, h->H, h->W, st);                   // rot_map
+    launch_tm_warp_nearest(d_roi, h->tmM1, a, h->H, h->W, st);                  // rot_roi
+    launch_gauss_rows(h->tmB, h->tmA, h->tm_kx, nx, 1, h->H, h->W, st);
+    launch_gauss_cols(h->tmA, h->tmB, h->tm_ky, ny, 1, h->H, h->W, st);         // blurred
+    launch_tm_warp_linear(h->tmB, h->tmA, ai, h->H, h->W, st);                  // back
+    launch_tm_warp_nearest(h->tmM1, h->tmM2, ai, h->H, h->W, st);               // back_roi
+    launch_tm_mask_nan(h->tmA, h->tmM2, d_out, P, st);
+    return tm_done("oriented blur");
 }
 
 }  // extern "C"

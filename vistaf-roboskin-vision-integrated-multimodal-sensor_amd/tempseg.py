@@ -47,6 +47,10 @@ CROP_PAD_PX = 10                                              # :49
 BLUR_KSIZE = 5                                                # :52
 COLOR_CHROMA_MIN = 10.0                                       # :86
 COLOR_SUPPORT_DILATE = 3                                      # :87
+COLOR_T_MIN, COLOR_T_MAX = 20.0, 33.0                         # :55-56
+COLOR_GUARD_BAND, SWITCH_MARGIN_C = 0.5, 1.0                  # :59-60
+FINAL_T_MIN, FINAL_T_MAX = 20.0, 75.0                         # :63-64
+FINAL_SMOOTH_SIGMA_ACROSS, FINAL_SMOOTH_SIGMA_ALONG = 6.0, 1.0   # :95-96
 
 
 def circle_from_three_points(p1, p2, p3, eps: float = 1e-12) -> Tuple[float, float, float]:
@@ -184,6 +188,54 @@ class TempSegmenter:
                                                            float(chroma_min), int(dilate_ksize), chroma.data_ptr(), support.data_ptr(), stream))
         return support.cpu().numpy().astype(bool), chroma.cpu().numpy()
 
+    # ---- third slice: the map-domain stages behind the regressors (parity unpinned, see include/vistaf_temp.h) ------------------------
+    def _dev_f32(self, m, what):
+        t = m if torch.is_tensor(m) else torch.from_numpy(np.ascontiguousarray(np.asarray(m), dtype=np.float32))
+        if tuple(t.shape) != (self.H, self.W) or t.dtype != torch.float32:
+            raise ValueError(f"{what} must be float32 [H, W]")
+        return t.to(self.device).contiguous()
+
+    def _stream(self):
+        return int(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def clamp_map(self, m, roi, lo: float, hi: float) -> np.ndarray:
+        """clamp_map (:538-543)"""
+        mp, r = self._dev_f32(m, "map"), self._dev_u8(roi, "roi")
+        out = torch.empty_like(mp)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.vistaf_temp_clamp_map(self._h, mp.data_ptr(), r.data_ptr(), float(lo), float(hi), out.data_ptr(), self._stream()))
+        return out.cpu().numpy()
+
+    def inpaint_temperature_map(self, temp_map, roi_mask, radius: int = 7) -> np.ndarray:
+        """inpaint_temperature_map (:546-580)"""
+        mp, r = self._dev_f32(temp_map, "map"), self._dev_u8(roi_mask, "roi")
+        out = torch.empty_like(mp)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.vistaf_temp_inpaint_map(self._h, mp.data_ptr(), r.data_ptr(), int(radius), out.data_ptr(), self._stream()))
+        return out.cpu().numpy()
+
+    def fuse_maps_per_pixel(self, roi, wide_map, color_map, fuse_config: Optional["_lib.CTempFuseConfig"] = None):
+        """fuse_maps_per_pixel (:594-636) -> (final float32, source uint8, dbg)"""
+        r, wm, cm = self._dev_u8(roi, "roi"), self._dev_f32(wide_map, "wide map"), self._dev_f32(color_map, "colour map")
+        fin = torch.empty_like(wm)
+        src = torch.empty((self.H, self.W), dtype=torch.uint8, device=self.device)
+        cfg = fuse_config or _lib.CTempFuseConfig(COLOR_T_MIN, COLOR_T_MAX, COLOR_GUARD_BAND, SWITCH_MARGIN_C, FINAL_T_MIN, FINAL_T_MAX)
+        counts = (ctypes.c_int64 * 4)()
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.vistaf_temp_fuse_maps(self._h, r.data_ptr(), wm.data_ptr(), cm.data_ptr(), ctypes.byref(cfg), fin.data_ptr(), src.data_ptr(),
+                                                       counts, self._stream()))
+        dbg = {"roi_pixels": int(counts[0]), "wide_ok_pixels": int(counts[1]), "color_ok_pixels": int(counts[2]), "blend_pixels": int(counts[3])}
+        return fin.cpu().numpy(), src.cpu().numpy(), dbg
+
+    def oriented_gaussian_blur_float(self, map_f, roi, angle_rad: float, sigma_across: float, sigma_along: float) -> np.ndarray:
+        """oriented_gaussian_blur_float (:705-747)"""
+        mp, r = self._dev_f32(map_f, "map"), self._dev_u8(roi, "roi")
+        out = torch.empty_like(mp)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.vistaf_temp_oriented_blur(self._h, mp.data_ptr(), r.data_ptr(), float(angle_rad), float(sigma_across), float(sigma_along),
+                                                           out.data_ptr(), self._stream()))
+        return out.cpu().numpy()
+
 
 _default: Optional[TempSegmenter] = None
 
@@ -207,6 +259,26 @@ def color_support_mask(planes, light_mask, roi_eff, sat, chroma_min: float = 10.
     """The colour-support test of temperature_sensor.main() (:793-799) -> (color_support, chroma)"""
     h, w = (int(v) for v in planes["a"].shape)
     return _session(h, w).color_support(planes, light_mask, roi_eff, sat, chroma_min, dilate_ksize)
+
+
+def clamp_map(m, roi, lo: float, hi: float) -> np.ndarray:
+    """Drop-in for temperature_sensor.clamp_map (:538)"""
+    return _session(*(int(v) for v in np.shape(m))).clamp_map(m, roi, lo, hi)
+
+
+def inpaint_temperature_map(temp_map, roi_mask, radius: int = 7) -> np.ndarray:
+    """Drop-in for temperature_sensor.inpaint_temperature_map (:546)"""
+    return _session(*(int(v) for v in np.shape(temp_map))).inpaint_temperature_map(temp_map, roi_mask, radius)
+
+
+def fuse_maps_per_pixel(roi, wide_map, color_map):
+    """Drop-in for temperature_sensor.fuse_maps_per_pixel (:594) with the constants as shipped (:55-64)"""
+    return _session(*(int(v) for v in np.shape(wide_map))).fuse_maps_per_pixel(roi, wide_map, color_map)
+
+
+def oriented_gaussian_blur_float(map_f, roi, angle_rad: float, sigma_across: float, sigma_along: float) -> np.ndarray:
+    """Drop-in for temperature_sensor.oriented_gaussian_blur_float (:705)"""
+    return _session(*(int(v) for v in np.shape(map_f))).oriented_gaussian_blur_float(map_f, roi, angle_rad, sigma_across, sigma_along)
 
 
 def segment_dark_light_gratings_periodic_fft(image_bgr, roi_full, config: Optional[TempSegConfig] = None):
