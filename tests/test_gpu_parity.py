@@ -776,3 +776,34 @@ def test_unwrap_consistency_check_against_flood_on_many_frames(pkg, cal):
     assert np.array_equal(sensor.intermediate("unwrapped", nb).cpu().numpy(), uw, equal_nan=True)
     assert np.array_equal(out2["height_map_mm"].cpu().numpy(), hm, equal_nan=True)
     assert (out["status"].cpu().numpy() == out2["status"].cpu().numpy()).all()
+
+
+def test_march_generation_overflow_is_handed_back(pkg, cal):
+    """The 16-wave march holds at most 2 048 entries per FMM generation (k_inpaint_mw.hip); a lattice of saturated dots gives ~120 separate 5 x 5
+    blobs in one window, i.e. more band pixels than that in generation 0.  Such a frame must come back from the single-wave tiers with the
+    oracle's plane, bit for bit, like any other frame -- with the 16-wave tier on and off."""
+    n = 224
+    cfg = pkg.FtpConfig.scaled(n)
+    ref, sensor = _sensor(pkg, cal, n, cfg, 2, config=3)
+    frames = pkg.synth.deformed_batch(n, 700, 2, config=3).copy()
+    for y in range(70, 158, 8):
+        for x in range(68, 156, 8):
+            frames[1][y, x] = 255
+    out = sensor.predict_batch(frames)
+    torch.cuda.synchronize()
+    img = sensor.intermediate("img", 2).cpu().numpy().reshape(2, n, n).copy()
+    bad = sensor.intermediate("bad1", 2, torch.uint8).cpu().numpy().reshape(2, n, n) != 0
+    rs = O.make_reference_state(ref, *pkg.synth.roi_circle(n), cfg)
+    for b in range(2):
+        o = O.process_frame(frames[b], rs, cfg, *cal, keep_intermediates=True)
+        di = o["inter"]["demod"]["inter"]
+        assert np.array_equal(bad[b], di["bad"]), b
+        assert np.array_equal(img[b], di["img_inpainted"]), b
+        _check_frame(out, b, o, n)
+    from oracle import cvlite
+    nseed = int((cvlite.dilate(bad[1].astype(np.uint8), np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]], np.uint8)) > 0).sum() - bad[1].sum())
+    assert nseed > 2048, nseed                                  # the frame does exceed a generation of the 16-wave tier
+    sensor._test_set("telea_mw", 0)
+    sensor.predict_batch(frames)
+    torch.cuda.synchronize()
+    assert np.array_equal(sensor.intermediate("img", 2).cpu().numpy().reshape(2, n, n), img)

@@ -457,12 +457,14 @@ __device__ __attribute__((always_inline)) inline void robust_polyfit_col_body(co
             if (lane == 0) s_part[wid][i] = v;
         }
         __syncthreads();
+        SEL_STAMP(11);
         if (tid < 21) {
             double v = 0.0;
             for (int k = 0; k < NT / 64; k++) v += s_part[k][tid];
             s_sum[tid] = v;
         }
         __syncthreads();
+        SEL_STAMP(12);
         if (tid == 0) {
             // monomial (a, b) -> index in v21: b-major with 5, 4, 3, 2, 1 entries
             auto mono = [&](int a, int bb) -> double { const int base[5] = {0, 5, 9, 12, 14}; return s_sum[base[bb] + a]; };
@@ -478,6 +480,7 @@ __device__ __attribute__((always_inline)) inline void robust_polyfit_col_body(co
 #pragma unroll
             for (int i = 0; i < 6; i++) s_coef[i] = (ok && i < nc) ? (float)rhs[i] : 0.f;
         }
+        SEL_STAMP(13);
         __syncthreads();
         for (int i = 0; i < 6; i++) coef[i] = s_coef[i];
         At = fmaf(coef[3], __fmul_rn(xn, xn), fmaf(coef[0], xn, coef[2]));
@@ -510,23 +513,29 @@ __device__ __attribute__((always_inline)) inline void robust_polyfit_col_body(co
     // residual plane: z - fit over the WHOLE plane, unfitted pixels included (fit evaluated as eval_poly2d does, :1093-1097, :1132-1135)
     float *out = resid_all + b * (size_t)P;
     if (owner) {
+        // fitted pixels still sit in the registers; the others (masked out or NaN upstream) are read again -- all of those loads first, in
+        // batches of independent requests (one dependent load per row made this loop a tenth of the kernel), then arithmetic and stores
 #pragma unroll
         for (int u = 0; u < RP; u++) {
             const int y = grp + groups * u;
-            if (y >= h) break;
-            // fitted pixels still sit in the registers; only the others (masked out or NaN) are read again
-            const float zin = finitef(zr[u]) ? zr[u] : z[(size_t)y * w + col];
-            float fit = 0.f;
-            if (do_fit) {
-                const float yn = s_yn[y];
-                fit = __fadd_rn(__fadd_rn(__fmul_rn(coef[0], xn), __fmul_rn(coef[1], yn)), coef[2]);
-                if (order >= 2) {
-                    fit = __fadd_rn(fit, __fmul_rn(__fmul_rn(coef[3], xn), xn));
-                    fit = __fadd_rn(fit, __fmul_rn(__fmul_rn(coef[4], xn), yn));
-                    fit = __fadd_rn(fit, __fmul_rn(__fmul_rn(coef[5], yn), yn));
+            if (y < h && !finitef(zr[u])) zr[u] = z[(size_t)y * w + col];
+        }
+#pragma unroll
+        for (int u = 0; u < RP; u++) {
+            const int y = grp + groups * u;
+            if (y < h) {
+                float fit = 0.f;
+                if (do_fit) {
+                    const float yn = s_yn[y];
+                    fit = __fadd_rn(__fadd_rn(__fmul_rn(coef[0], xn), __fmul_rn(coef[1], yn)), coef[2]);
+                    if (order >= 2) {
+                        fit = __fadd_rn(fit, __fmul_rn(__fmul_rn(coef[3], xn), xn));
+                        fit = __fadd_rn(fit, __fmul_rn(__fmul_rn(coef[4], xn), yn));
+                        fit = __fadd_rn(fit, __fmul_rn(__fmul_rn(coef[5], yn), yn));
+                    }
                 }
+                out[(size_t)y * w + col] = __fsub_rn(zr[u], fit);
             }
-            out[(size_t)y * w + col] = __fsub_rn(zin, fit);
         }
     }
     SEL_STAMP(9);
@@ -538,7 +547,7 @@ void fit_debug_dump()
     unsigned long long d[16];
     if (hipMemcpyFromSymbol(d, HIP_SYMBOL(g_fit_dbg), sizeof(d)) != hipSuccess) return;
     printf("[fit dbg] frame 0, %llu launches so far, cycle sums: load %llu | column sums %llu | reduce+solve %llu | hist clear %llu | hist pass %llu | bucket search %llu | "
-           "collect %llu | sort %llu | second statistic pass %llu | residual plane %llu\n", d[10], d[8], d[6], d[7], d[0], d[1], d[2], d[3], d[4], d[5], d[9]);
+           "collect %llu | sort %llu | second statistic pass %llu | residual plane %llu || of reduce+solve: wave sums %llu | partials %llu | solve %llu | rest in [reduce+solve]\n", d[10], d[8], d[6], d[7], d[0], d[1], d[2], d[3], d[4], d[5], d[9], d[11], d[12], d[13]);
 }
 #endif
 
