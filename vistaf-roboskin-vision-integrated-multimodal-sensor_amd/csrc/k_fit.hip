@@ -405,9 +405,11 @@ __device__ __attribute__((always_inline)) inline void robust_polyfit_col_body(co
         asm volatile("" : "+s"(g0));
 #pragma unroll
         for (int u = 0; u < RP; u++) {
-            const float zz = zr[u];
-            if (finitef(zz)) {
-                float r = resid_of(g0, u, zz);
+            // the test is on the RESIDUAL (NaN for a sample that is not fitted), not on the sample: "is zr[u] finite" is invariant across
+            // the IRLS loop, so the compiler kept all RP answers as exec masks in SGPRs (450 of them spilled to VGPR lanes and read
+            // back with two v_readlane per sample and sweep)
+            float r = resid_of(g0, u, zr[u]);
+            if (finitef(r)) {
                 if (mode) r = fabsf(__fsub_rn(r, med));
                 body(f2key(r));
             }
@@ -424,7 +426,7 @@ __device__ __attribute__((always_inline)) inline void robust_polyfit_col_body(co
 #pragma unroll
         for (int u = 0; u < RP; u++) {
             const float zz = zr[u];
-            if (finitef(zz)) {
+            if (finitef(__fmul_rn(zz, inv_csig))) {               // (finite exactly when zz is; not invariant across the IRLS loop, see `each`)
                 float wt = 1.f;
                 if (it > 0) {
                     const float uu = __fmul_rn(resid_of(g0, u, zz), inv_csig);
