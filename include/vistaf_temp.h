@@ -12,6 +12,10 @@
  * or a negative VISTAF_E_* code (vistaf_ftp.h); vistaf_ftp_last_error() holds the message.  The full-frame spectrum of the carrier search
  * is a plain library transform (hipFFT, float32: only the POSITION of the strongest peaks is read from it); the band-pass around the chosen
  * carrier is the library's own pruned float64 DFT on the matrix cores, everything else hand-written HIP.
+ * Known numerical differences from upstream, both without effect on the five stored demo photographs (0 differing mask pixels): the peak
+ * search ranks float32 magnitudes where upstream ranks float64 ones (two peaks within float32 rounding of each other could swap), and the
+ * mean of the normalised image is a float64 sum rounded once where np.mean accumulates pairwise in float32 (a stripe-edge pixel whose
+ * band-passed value is within an ulp of 0 could flip).  Pixel-for-pixel parity is pinned on those photographs only.
  */
 #ifndef VISTAF_TEMP_H
 #define VISTAF_TEMP_H

@@ -80,18 +80,26 @@ __device__ inline int wave_excl_scan(int v, int lane, int &total)
     return s - v;
 }
 
-// the pops of one generation on one wave: claim the next entry in pop order, wait until the earlier entries in reach have popped, pop it,
-// release the later entries in reach.  ORDER: the march's ordering pass (states in the fill-number plane), else the outside pass (states in the flag bytes)
+// The pops of one generation on one wave.  A pop needs 16 lanes (4 neighbours x 4 quadrants), so the wave holds FOUR entries at a time, one
+// per 16-lane group: 64 entries of the generation are held by the workgroup's waves, claimed in pop order (the first entry that has not
+// popped yet is therefore always held and has no open dependence: the loop makes progress whatever the others wait for).  Every turn a group
+// without an entry claims the next one, every group looks at its entry's counter of earlier entries in reach that have not popped yet, and the
+// groups whose counter is 0 pop together -- two such entries are never in reach of each other (the later one would be waiting for the earlier).
+// ORDER: the march's ordering pass (states in the fill-number plane), else the outside pass (states in the flag bytes).
 template <bool ORDER>
 __device__ __attribute__((always_inline)) inline void gp_pop_loop(const GenScratch &S, float *t, uint8_t *f, uint16_t *fi, int M, int g, int wh, int ww,
                                                                   uint32_t mg_ww, int lane)
 {
-    const TeleaOutsideConsts oc = telea_outside_consts(lane, ww);       // lanes 0..15 = 4 neighbours x 4 quadrants
-    const int nbi = (lane >> 2) & 3;
-    // the 24 cells within Manhattan distance 3, one per lane
-    int ndy = 0, ndx = 0;
-    {
-        int i = lane;
+    const TeleaOutsideConsts oc = telea_outside_consts(lane, ww);       // per 16-lane group: 4 neighbours x 4 quadrants
+    const int nbi = (lane >> 2) & 3, grp = lane >> 4, li = lane & 15;
+    // the 24 cells within Manhattan distance 3: lane li of a group takes cells li and li + 16
+    int ndy[2], ndx[2];
+    bool non[2];
+#pragma unroll
+    for (int c2 = 0; c2 < 2; c2++) {
+        int i = li + 16 * c2;
+        non[c2] = i < 24;
+        ndy[c2] = 0; ndx[c2] = 0;
         const int rows[7] = {1, 3, 5, 6, 5, 3, 1};
         int dy = -3;
 #pragma unroll
@@ -100,63 +108,64 @@ __device__ __attribute__((always_inline)) inline void gp_pop_loop(const GenScrat
                 const int rad = 3 - (dy < 0 ? -dy : dy);
                 int dx = i - rad;
                 if (dy == 0 && dx >= 0) dx++;              // skip the centre
-                ndy = dy; ndx = dx;
+                ndy[c2] = dy; ndx[c2] = dx;
             }
             i -= rows[k];
             dy++;
         }
     }
-    const bool non = lane < 24;
-    const int noff = ndy * ww + ndx;
+    const unsigned long long below_grp = (1ull << (16 * grp)) - 1ull;
     int *ctl = S.ctl;
+    int r = -1, p = 0;                  // this group's entry (rank in the generation, cell); -1: none
+    bool spent = false;                 // the generation has no entry left to claim
+    // a pop's pushes wait in registers until the wave has nothing to pop: queue insertions and claims (LDS atomics with a return value) are
+    // housekeeping, the time between "the counter reads 0" and "the dependants' counters are decremented" is the workgroup's critical path
+    bool plead = false;
+    float pdist = 0.f;
+    int ppn = 0, pr = 0;
     for (;;) {
-        // entries are claimed in pop order: the first entry that has not popped yet is always held by a wave and has no open dependence,
-        // so the loop makes progress whatever the other waves wait for
-        int ri = 0;
-        if (lane == 0) ri = atomicAdd(&ctl[MWC_HEAD], 1);
-        ri = __builtin_amdgcn_readfirstlane(ri);
-        if (ri >= M) break;
-        const unsigned r = (unsigned)ri;
-        const int p = (int)((uint32_t)S.gen[r] & 0x3FFFu);
-        const int pn = p + oc.dn, p1 = pn + oc.d1, p2 = pn + oc.d2;
-        const int py = (int)__umulhi((uint32_t)p, mg_ww), px = p - py * ww;
-        const bool nin = non && py + ndy >= 0 && py + ndy < wh && px + ndx >= 0 && px + ndx < ww;
-        const int pq = nin ? p + noff : p;
-        while (__hip_atomic_load(&S.dep[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) __builtin_amdgcn_s_sleep(1);
-        // every read of the pop in one round: the neighbour's state, the two arguments of its quadrant (lanes beyond the 16 read, unused,
-        // cells next to p; an address outside the window's planes returns junk nobody looks at), the rank marks around p (entries that
-        // wait for this pop keep their mark until they pop themselves)
-        float a11 = t[p1], a22 = t[p2];
-        bool in0, in1, in2;
-        if (ORDER) { const uint16_t s0 = fi[pn], s1 = fi[p1], s2 = fi[p2]; in0 = s0 == FI_INSIDE; in1 = s1 == FI_INSIDE; in2 = s2 == FI_INSIDE; }
-        else { const uint8_t s0 = f[pn], s1 = f[p1], s2 = f[p2]; in0 = (s0 & W_ST) == W_INSIDE; in1 = (s1 & W_ST) == W_INSIDE; in2 = (s2 & W_ST) == W_INSIDE; }
-        const unsigned v = fi[pq];
-        const bool ok = lane < 16 && in0;
-        const unsigned long long okb = __ballot(ok);
-        float dist = wn_solve(a11, a22, !in1, !in2);
-        {
-            float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dist), 0xB1, 0xf, 0xf, false)); dist = o < dist ? o : dist;
-            o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dist), 0x4E, 0xf, 0xf, false)); dist = o < dist ? o : dist;
+        const bool ready = r >= 0 && __hip_atomic_load(&S.dep[r >= 0 ? r : 0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u;
+        if (__ballot(ready)) {
+            if (ready) {
+                const int pn = p + oc.dn, p1 = pn + oc.d1, p2 = pn + oc.d2;
+                const int py = (int)__umulhi((uint32_t)p, mg_ww), px = p - py * ww;
+                const bool nin0 = non[0] && py + ndy[0] >= 0 && py + ndy[0] < wh && px + ndx[0] >= 0 && px + ndx[0] < ww;
+                const bool nin1 = non[1] && py + ndy[1] >= 0 && py + ndy[1] < wh && px + ndx[1] >= 0 && px + ndx[1] < ww;
+                // every read of the pop in one round: the neighbour's state, the two arguments of its quadrant (an address outside the window's
+                // planes returns junk nobody looks at), the rank marks around p (entries that wait for this pop keep their mark until they pop)
+                const float a11 = t[p1], a22 = t[p2];
+                bool in0, in1, in2;
+                if (ORDER) { const uint16_t s0 = fi[pn], s1 = fi[p1], s2 = fi[p2]; in0 = s0 == FI_INSIDE; in1 = s1 == FI_INSIDE; in2 = s2 == FI_INSIDE; }
+                else { const uint8_t s0 = f[pn], s1 = f[p1], s2 = f[p2]; in0 = (s0 & W_ST) == W_INSIDE; in1 = (s1 & W_ST) == W_INSIDE; in2 = (s2 & W_ST) == W_INSIDE; }
+                const unsigned v0 = fi[nin0 ? p + ndy[0] * ww + ndx[0] : p], v1 = fi[nin1 ? p + ndy[1] * ww + ndx[1] : p];
+                float dist = wn_solve(a11, a22, !in1, !in2);
+                {
+                    float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dist), 0xB1, 0xf, 0xf, false)); dist = o < dist ? o : dist;
+                    o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dist), 0x4E, 0xf, 0xf, false)); dist = o < dist ? o : dist;
+                }
+                if (li == 0) {                          // the entry leaves the queue (this also drops its rank mark)
+                    if (ORDER) fi[p] = g == 0 ? FI_NOHOLE : FI_FILLED;
+                    else { f[p] = (uint8_t)(g == 0 ? (W_SEED | W_CHANGE) : W_CHANGE); fi[p] = FI_NOHOLE; }
+                }
+                plead = in0 && (li & 3) == 0;
+                pdist = dist; ppn = pn; pr = r;
+                if (plead) {
+                    t[pn] = dist;
+                    if (ORDER) fi[pn] = FI_FILLED; else f[pn] = W_BAND;
+                }
+                // release the later entries in reach.  The stores above and the decrements below are LDS operations of one wave: the LDS
+                // unit executes them in issue order, so a wave that sees its counter at 0 sees the stores (no s_waitcnt between them: the
+                // compiler only has to keep the order)
+                asm volatile("" ::: "memory");
+                const unsigned rv0 = v0 & 0x7FFFu, rv1 = v1 & 0x7FFFu;
+                if (nin0 && (v0 & FI_PEND) && rv0 > (unsigned)r) __hip_atomic_fetch_sub(&S.dep[rv0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (nin1 && (v1 & FI_PEND) && rv1 > (unsigned)r) __hip_atomic_fetch_sub(&S.dep[rv1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                r = -1;
+            }
+            continue;                                   // look at the counters again before any housekeeping
         }
-        if (lane == 0) {                          // the entry leaves the queue (this also drops its rank mark)
-            if (ORDER) fi[p] = g == 0 ? FI_NOHOLE : FI_FILLED;
-            else { f[p] = (uint8_t)(g == 0 ? (W_SEED | W_CHANGE) : W_CHANGE); fi[p] = FI_NOHOLE; }
-        }
-        const unsigned long long pb = okb & 0x1111ull;
-        const bool lead = (pb >> lane) & 1ull;
-        if (lead) {
-            t[pn] = dist;
-            if (ORDER) fi[pn] = FI_FILLED; else f[pn] = W_BAND;
-        }
-        // release the later entries in reach.  The stores above and the decrements below are LDS operations of one wave: the LDS unit
-        // executes them in issue order, so a wave that sees its counter at 0 sees the stores (no s_waitcnt between them: the compiler only
-        // has to keep the order)
-        asm volatile("" ::: "memory");
-        {
-            const unsigned rv = v & 0x7FFFu;
-            if (nin && (v & FI_PEND) && rv > r) __hip_atomic_fetch_sub(&S.dep[rv], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        // the pushes (off the other waves' critical path)
+        // ---- nothing to pop: housekeeping.  First the pushes of the pops since the last time ...
+        const unsigned long long pb = __ballot(plead);
         if (pb) {
             const int cnt = __popcll(pb);
             int base = 0;
@@ -164,11 +173,28 @@ __device__ __attribute__((always_inline)) inline void gp_pop_loop(const GenScrat
             base = __builtin_amdgcn_readfirstlane(base);
             const bool fits = base + cnt <= GP_POOL;
             if (!fits && lane == 0) ctl[MWC_FAIL] = 1;
-            if (lead) {
-                if (fits) S.pool[base + __popcll(pb & ((1ull << lane) - 1ull))] = gp_key(dist, g, (int)r, nbi, pn);
-                if (ORDER) atomicOr(&S.bitmap[(r * 4 + nbi) >> 5], 1u << ((r * 4 + nbi) & 31));
+            if (plead) {
+                if (fits) S.pool[base + __popcll(pb & ((1ull << lane) - 1ull))] = gp_key(pdist, g, pr, nbi, ppn);
+                if (ORDER) atomicOr(&S.bitmap[((unsigned)pr * 4 + nbi) >> 5], 1u << (((unsigned)pr * 4 + nbi) & 31));
             }
+            plead = false;
         }
+        // ... then the next entries for the groups that have none
+        const bool want = r < 0 && !spent;
+        const unsigned long long wb = __ballot(want && li == 0);
+        if (wb) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&ctl[MWC_HEAD], __popcll(wb));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (want) {
+                const int mine = base + __popcll(wb & below_grp);
+                if (mine < M) { r = mine; p = (int)((uint32_t)S.gen[mine] & 0x3FFFu); }
+                else spent = true;
+            }
+            continue;
+        }
+        if (!__ballot(r >= 0)) break;                   // every group is out of entries and every push is queued
+        __builtin_amdgcn_s_sleep(1);
     }
 }
 
@@ -336,25 +362,26 @@ __device__ __attribute__((always_inline)) inline void mw_fill_loop(const TeleaWi
         if (lane == 0) s = atomicAdd(&ctl[MWC_HEAD], 1);
         s = __builtin_amdgcn_readfirstlane(s);
         if (s >= nfill) break;                   // every fill is queued exactly once: slots [0, nfill) all get an entry
-        unsigned k;
-        while ((k = __hip_atomic_load(&rq[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0xFFFFFFFFu) __builtin_amdgcn_s_sleep(1);
-        k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const int pi = flist[k];
+        unsigned e;                              // fill number | cell << 16
+        while ((e = __hip_atomic_load(&rq[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0xFFFFFFFFu) __builtin_amdgcn_s_sleep(1);
+        e = (unsigned)__builtin_amdgcn_readfirstlane((int)e);
+        const unsigned k = e & 0xFFFFu;
+        const int pi = (int)(e >> 16);
+        // the fill numbers around pi are read before the estimate (they do not change), the counters of the later ones are decremented
+        // right behind its stores: LDS operations of one wave execute in issue order, no wait is needed between them
+        const unsigned c0 = non[0] ? fi[pi + noff[0]] : 0u, c1 = non[1] ? fi[pi + noff[1]] : 0u;
         telea_fill_known_T<NS>(win, mc, pi, lane);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        auto release = [&](bool on, int off) {
-            if (!on) return;
-            const unsigned c = fi[pi + off];
+        asm volatile("" ::: "memory");
+        auto release = [&](unsigned c) {
             if (c > k && c < FI_FILLED) {
                 if (atomicSub(&dep[c], 1u) == 1u) {
                     const int slot = atomicAdd(&ctl[MWC_TAIL], 1);
-                    __hip_atomic_store(&rq[slot], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(&rq[slot], c | ((unsigned)flist[c] << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
         };
-        release(non[0], noff[0]);
-        release(non[1], noff[1]);
+        release(c0);
+        release(c1);
     }
 }
 
@@ -520,7 +547,7 @@ __global__ __launch_bounds__(MW_T) void k_telea_window_mw(float *__restrict__ im
                 for (int dl = -D; dl <= D; dl++) cnt += row[dl] < (unsigned)k ? 1u : 0u;       // FI_NOHOLE is not
             }
             dep[k] = cnt;
-            if (cnt == 0) { const int slot = atomicAdd(&ctl[MWC_TAIL], 1); rq[slot] = (uint32_t)k; }
+            if (cnt == 0) { const int slot = atomicAdd(&ctl[MWC_TAIL], 1); rq[slot] = (uint32_t)k | ((uint32_t)pi << 16); }
         }
     }
     __syncthreads();
