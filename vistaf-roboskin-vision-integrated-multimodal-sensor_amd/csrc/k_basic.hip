@@ -458,18 +458,33 @@ __global__ __launch_bounds__(256) void k_gauss_fused(const float *__restrict__ s
     const int x0 = blockIdx.x * GF_TX, y0 = blockIdx.y * GF_TY;
     const size_t b = blockIdx.z;
     const float *plane = src + b * (size_t)h * w;
-    for (int i = threadIdx.x; i < tw * th; i += 256) {
-        const int ty = i / tw, tx = i - ty * tw;
-        in_t[i] = plane[(size_t)reflect101(y0 + ty - r, h) * w + reflect101(x0 + tx - r, w)];
+    // tile with halo: a wave per tile row, the lane's (at most two) source columns reflected once
+    {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const int sx0 = reflect101(x0 + lane - r, w), sx1 = reflect101(x0 + lane + 64 - r, w);
+        const bool two = lane + 64 < tw;
+        for (int ty = wv; ty < th; ty += 4) {
+            const float *row = plane + (size_t)reflect101(y0 + ty - r, h) * w;
+            in_t[ty * tw + lane] = row[sx0];
+            if (two) in_t[ty * tw + lane + 64] = row[sx1];
+        }
     }
     __syncthreads();
-    // row pass: th rows x 64 columns
-    for (int i = threadIdx.x; i < th * GF_TX; i += 256) {
-        const int ty = i >> 6, tx = i & 63;
+    // row pass: th rows x 64 columns, FOUR adjacent outputs per thread out of one sliding window of taps (ksize + 3 LDS reads instead of
+    // 4 ksize); every output is still  s = k[0] S[0]; s = fma(k[j], S[j], s)  in ascending j
+    for (int q = threadIdx.x; q < th * 16; q += 256) {
+        const int ty = q >> 4, tx = (q & 15) * 4;
         const float *t = in_t + ty * tw + tx;
-        float acc = kern[0] * t[0];
-        for (int j = 1; j < ksize; j++) acc = fmaf(kern[j], t[j], acc);
-        mid_t[i] = acc;
+        float v0 = t[0], v1 = t[1], v2 = t[2], v3 = t[3];
+        const float k0 = kern[0];
+        float a0 = k0 * v0, a1 = k0 * v1, a2 = k0 * v2, a3 = k0 * v3;
+        for (int j = 1; j < ksize; j++) {
+            v0 = v1; v1 = v2; v2 = v3; v3 = t[j + 3];
+            const float kj = kern[j];
+            a0 = fmaf(kj, v0, a0); a1 = fmaf(kj, v1, a1); a2 = fmaf(kj, v2, a2); a3 = fmaf(kj, v3, a3);
+        }
+        float *m = mid_t + ty * GF_TX + tx;
+        m[0] = a0; m[1] = a1; m[2] = a2; m[3] = a3;
     }
     __syncthreads();
     // column pass: symmetric sum over GC_R output rows of one column (gauss_col_symm)
