@@ -87,6 +87,7 @@ struct vistaf_ftp_handle {
     unsigned int *peak_bits;
     uint16_t *morph_pre;
     void *inpaint_scratch, *inpaint_cl_scratch, *inpaint_win_scratch, *unwrap_scratch;
+    void *big_scratch = nullptr;      // k_big.hip (frames of 512 x 512 and more), else null
     int32_t *unwrap_need;       // [max_batch] 1: the frame went through the priority flood, 0: the consistency check settled it
     // small per-frame arrays
     float *thr_hi, *thr_g, *mu, *amp_thr, *thr3, *thr_used, *bg_med, *core_thr, *core_med, *coef;
@@ -206,8 +207,8 @@ void preprocess(vistaf_ftp_handle *hd, const void *frames, int format, int nfram
     hipMemsetAsync(hd->bad_count, 0, sizeof(int) * B, st);
     if (c.bad_pixel_enable) {
         launch_sobel_mag(hd->img, hd->grad, B, h, w, st);
-        launch_select(hd->img, hd->valid, 0, nullptr, false, hd->req_hi, 1, hd->thr_hi, hd->cnt_valid, B, P, st);
-        launch_select(hd->grad, hd->valid, 0, nullptr, false, hd->req_g, 1, hd->thr_g, nullptr, B, P, st);
+        launch_select(hd->img, hd->valid, 0, nullptr, false, hd->req_hi, 1, hd->thr_hi, hd->cnt_valid, B, P, st, hd->tiers.big_chain ? hd->big_scratch : nullptr);
+        launch_select(hd->grad, hd->valid, 0, nullptr, false, hd->req_g, 1, hd->thr_g, nullptr, B, P, st, hd->tiers.big_chain ? hd->big_scratch : nullptr);
         launch_bad_flags(hd->img, hd->grad, hd->valid, hd->thr_hi, hd->thr_g, hd->bad0, B, P, st);
         uint8_t *src = hd->bad0, *dst = hd->bad1;
         if (c.bad_dilate_ksize > 1)
@@ -247,7 +248,7 @@ void preprocess(vistaf_ftp_handle *hd, const void *frames, int format, int nfram
     const float *in = hd->inorm;
     if (hd->g_pre.k) { blur(hd, hd->inorm, hd->blurA, hd->g_pre, B, st); in = hd->blurA; }
     launch_mul_static(in, hd->apo, hd->iw, B, P, st);
-    launch_select(hd->iw, hd->valid, 0, nullptr, false, hd->req_med, 1, hd->mu, nullptr, B, P, st);
+    launch_select(hd->iw, hd->valid, 0, nullptr, false, hd->req_med, 1, hd->mu, nullptr, B, P, st, hd->tiers.big_chain ? hd->big_scratch : nullptr);
 }
 
 // np.hanning(ph)[:,None] * np.hanning(pw)[None,:] in float32 (shape_ftp.py:800-807); np.hanning(M) = 0.5 + 0.5*cos(pi*n/(M-1)), n = 1-M, 3-M, ...
@@ -385,6 +386,7 @@ int vistaf_ftp_create(const vistaf_ftp_config *cfg, int h, int w, int cx, int cy
         TRY(dalloc(hd, (uint8_t **)&p, inpaint_cl_scratch_bytes_per_frame(h, w) * max_batch + 2048)); hd->inpaint_cl_scratch = p;
         TRY(dalloc(hd, (uint8_t **)&p, inpaint_win_scratch_bytes(max_batch))); hd->inpaint_win_scratch = p;
         TRY(dalloc(hd, (uint8_t **)&p, unwrap_scratch_bytes_per_frame(h, w) * max_batch + 1024)); hd->unwrap_scratch = p;
+        if ((size_t)h * w >= 262144) { TRY(dalloc(hd, (uint8_t **)&p, big_scratch_bytes(max_batch, h, w))); hd->big_scratch = p; }
         TRY(dalloc(hd, &hd->unwrap_need, (size_t)max_batch, "unwrap_need", sizeof(int32_t)));
         HIPCHK(hipMemset(hd->unwrap_need, 0xff, (size_t)max_batch * sizeof(int32_t)));        // -1: never written (the check is off or does not cover this frame size)
     }
@@ -532,7 +534,7 @@ static int post_demod(vistaf_ftp_handle *hd, int B, float *d_height_mm, uint8_t 
     if (hd->g_qual.k) { blur(hd, hd->prod, hd->quality, hd->g_qual, B, st); qual = hd->quality; }
     else HIPCHK(hipMemcpyAsync(hd->quality, hd->prod, (size_t)B * P * sizeof(float), hipMemcpyDeviceToDevice, st));
     qual = hd->quality;
-    launch_select(qual, hd->roi, 0, nullptr, false, hd->req_amp, 1, hd->amp_thr, nullptr, B, P, st);
+    launch_select(qual, hd->roi, 0, nullptr, false, hd->req_amp, 1, hd->amp_thr, nullptr, B, P, st, hd->tiers.big_chain ? hd->big_scratch : nullptr);
     launch_threshold_mask(qual, hd->roi, hd->amp_thr, hd->rel0, B, P, st);
     {
         // MORPH_CLOSE with n iterations = n dilations then n erosions; the eroded-ROI mask applies to the result
@@ -576,11 +578,11 @@ static int post_demod(vistaf_ftp_handle *hd, int B, float *d_height_mm, uint8_t 
     if (timed) hipEventRecord(hd->ev[ST_DETREND], st);
     if (c.plane_order_for_removal > 0)
         // debug_ramp gates on the reliable count, NaN pixels included (:1364-1366), robust_polyfit2d on 200 finite samples (:1103)
-        launch_robust_polyfit(hd->unwrapped, hd->reliable, c.plane_order_for_removal, c.irls_iters, (float)c.irls_c, 200, 500, hd->coef, hd->phase1, B, h, w, st, hd->tiers.fit_capped);
+        launch_robust_polyfit(hd->unwrapped, hd->reliable, c.plane_order_for_removal, c.irls_iters, (float)c.irls_c, 200, 500, hd->coef, hd->phase1, B, h, w, st, hd->tiers.fit_capped, hd->tiers.big_chain ? hd->big_scratch : nullptr);
     else   // no debug_ramp (the constants of Code/phase_to_height.py): the unwrapped phase goes to the detrend as it is
         HIPCHK(hipMemcpyAsync(hd->phase1, hd->unwrapped, (size_t)B * P * sizeof(float), hipMemcpyDeviceToDevice, st));
-    launch_robust_polyfit(hd->phase1, hd->reliable, c.poly_order, c.irls_iters, (float)c.irls_c, 200, 0, hd->coef, hd->resid0, B, h, w, st, hd->tiers.fit_capped);
-    launch_select(hd->resid0, hd->reliable, (size_t)P, nullptr, true, hd->req_contact, 3, hd->thr3, nullptr, B, P, st);
+    launch_robust_polyfit(hd->phase1, hd->reliable, c.poly_order, c.irls_iters, (float)c.irls_c, 200, 0, hd->coef, hd->resid0, B, h, w, st, hd->tiers.fit_capped, hd->tiers.big_chain ? hd->big_scratch : nullptr);
+    launch_select(hd->resid0, hd->reliable, (size_t)P, nullptr, true, hd->req_contact, 3, hd->thr3, nullptr, B, P, st, hd->tiers.big_chain ? hd->big_scratch : nullptr);
     launch_contact_mask(hd->resid0, hd->reliable, hd->thr3, hd->rel_count, hd->contact_count, (float)c.min_contact_frac, (float)c.max_contact_frac,
                         hd->contact, hd->thr_used, B, P, st);
     {
@@ -600,8 +602,8 @@ static int post_demod(vistaf_ftp_handle *hd, int B, float *d_height_mm, uint8_t 
         }
     }
     launch_background(hd->reliable, hd->contact_d, hd->rel_count, hd->bg_count, hd->background, B, P, st);
-    launch_robust_polyfit(hd->phase1, hd->background, c.poly_order, c.irls_iters, (float)c.irls_c, 200, 0, hd->coef, hd->detr, B, h, w, st, hd->tiers.fit_capped);
-    launch_select(hd->detr, hd->background, (size_t)P, nullptr, false, hd->req_med, 1, hd->bg_med, nullptr, B, P, st);
+    launch_robust_polyfit(hd->phase1, hd->background, c.poly_order, c.irls_iters, (float)c.irls_c, 200, 0, hd->coef, hd->detr, B, h, w, st, hd->tiers.fit_capped, hd->tiers.big_chain ? hd->big_scratch : nullptr);
+    launch_select(hd->detr, hd->background, (size_t)P, nullptr, false, hd->req_med, 1, hd->bg_med, nullptr, B, P, st, hd->tiers.big_chain ? hd->big_scratch : nullptr);
 
     // ---- reliable-only smoothing + sign flip (shape_ftp.py:1753-1768)
     if (timed) hipEventRecord(hd->ev[ST_SMOOTH_FLIP], st);
@@ -612,8 +614,8 @@ static int post_demod(vistaf_ftp_handle *hd, int B, float *d_height_mm, uint8_t 
         blur(hd, hd->mplane, hd->den, hd->g_rel, B, st);
         launch_div_planes(hd->num, hd->den, hd->hmap, B, P, st);
     } else launch_zeroed_keep_nan(hd->detr, hd->bg_med, hd->reliable, hd->hmap, B, P, st);      // NaN stays NaN: the hole stage below is live
-    launch_select(hd->hmap, hd->reliable, (size_t)P, nullptr, false, hd->req_core, 1, hd->core_thr, nullptr, B, P, st);
-    launch_select(hd->hmap, hd->reliable, (size_t)P, hd->core_thr, false, hd->req_med, 1, hd->core_med, nullptr, B, P, st);
+    launch_select(hd->hmap, hd->reliable, (size_t)P, nullptr, false, hd->req_core, 1, hd->core_thr, nullptr, B, P, st, hd->tiers.big_chain ? hd->big_scratch : nullptr);
+    launch_select(hd->hmap, hd->reliable, (size_t)P, hd->core_thr, false, hd->req_med, 1, hd->core_med, nullptr, B, P, st, hd->tiers.big_chain ? hd->big_scratch : nullptr);
     launch_core_flip(hd->hmap, hd->core_med, hd->flipped, B, P, st);
 
     // ---- internal holes of the reliable region (shape_ftp.py:1770-1801): with the smoothing every reliable pixel is finite here and
@@ -623,9 +625,9 @@ static int post_demod(vistaf_ftp_handle *hd, int B, float *d_height_mm, uint8_t 
         const int ksz = std::max(3, c.hole_neighborhood_px | 1);
         launch_chamfer(hd->reliable, false, hd->rowdist, hd->dist, B, h, w, c.hole_min_dist_px + 1, st, hd->tiers.chamfer_twopass != 0);
         launch_hole_candidates(hd->hmap, hd->reliable, hd->dist, ksz, (float)c.hole_known_fraction, (float)c.hole_min_dist_px, hd->hole_cand, B, h, w, st);
-        launch_select(hd->hmap, hd->reliable, (size_t)P, nullptr, false, hd->req_med, 1, hd->hole_med, nullptr, B, P, st);
+        launch_select(hd->hmap, hd->reliable, (size_t)P, nullptr, false, hd->req_med, 1, hd->hole_med, nullptr, B, P, st, hd->tiers.big_chain ? hd->big_scratch : nullptr);
         launch_hole_tmp(hd->hmap, hd->reliable, hd->hole_cand, hd->hole_med, hd->z0, B, P, st);
-        launch_select(hd->z0, hd->reliable, (size_t)P, nullptr, false, hd->req_med, 1, hd->hole_fill, nullptr, B, P, st);
+        launch_select(hd->z0, hd->reliable, (size_t)P, nullptr, false, hd->req_med, 1, hd->hole_fill, nullptr, B, P, st, hd->tiers.big_chain ? hd->big_scratch : nullptr);
         launch_hole_zin(hd->z0, hd->hole_fill, B, P, st);
         {
             const int range = std::min(100, std::max(1, cv_round((double)c.inpaint_radius)));
@@ -810,6 +812,7 @@ int vistaf_ftp_test_set(vistaf_ftp_handle *hd, const char *name, int value)
     else if (n == "fit_capped") hd->tiers.fit_capped = value != 0;
     else if (n == "telea_mw") hd->tiers.telea_mw = value != 0;
     else if (n == "unwrap_fast") hd->tiers.unwrap_fast = value != 0;
+    else if (n == "big_chain") hd->tiers.big_chain = value != 0;
     else if (n == "keep_planes") hd->keep_planes = value != 0;
     else return fail(VISTAF_E_INVALID, "unknown test hook or value: " + n);
     return 0;

@@ -569,8 +569,12 @@ __global__ __launch_bounds__(SEL_T) __attribute__((amdgpu_waves_per_eu(5, 5))) v
 // min_count: 200 fitted pixels upstream (:1103); min_mask_count: 500 mask pixels for the debug_ramp call (shape_ftp.py:1364-1366), else 0
 // capped: 1 = prefer the register-capped variant where it exists (RP 56, four row groups), 0 = 128-VGPR variants only
 void launch_robust_polyfit(const float *z, const uint8_t *mask, int order, int iters, float c, int min_count, int min_mask_count, float *coef_out,
-                           float *resid_out, int B, int h, int w, hipStream_t st, int capped)
+                           float *resid_out, int B, int h, int w, hipStream_t st, int capped, void *big_scratch)
 {
+    if (big_scratch && big_frames(B, h * w)) {                   // large frames: every sweep over all pixels of the batch (k_big.hip)
+        launch_robust_polyfit_big(z, mask, order, iters, c, min_count, min_mask_count, coef_out, resid_out, B, h, w, big_scratch, st);
+        return;
+    }
     // i / w == umulhi(i, magic) for every i < h * w as long as h * w * w < 2^32
     const uint32_t magic = ((unsigned long long)h * w * w < 0x100000000ull) ? (uint32_t)(0x100000000ull / (unsigned)w) + 1u : 0u;
     const int cols_pad = ((w + 63) / 64) * 64;

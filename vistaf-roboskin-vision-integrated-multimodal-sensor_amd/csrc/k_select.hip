@@ -40,8 +40,12 @@ __global__ __launch_bounds__(SEL_T) void k_select(const float *__restrict__ vals
 }
 
 void launch_select(const float *vals, const uint8_t *mask, size_t mask_stride, const float *le_thr, bool use_abs,
-                   const float *reqs_dev, int nreq, float *out, int *counts, int B, int P, hipStream_t st)
+                   const float *reqs_dev, int nreq, float *out, int *counts, int B, int P, hipStream_t st, void *big_scratch)
 {
+    if (big_scratch && nreq <= 4 && big_frames(B, P)) {          // large frames: every sweep over all pixels of the batch (k_big.hip)
+        launch_select_big(vals, mask, mask_stride, le_thr, use_abs, reqs_dev, nreq, out, counts, B, P, big_scratch, st);
+        return;
+    }
     hipLaunchKernelGGL(k_select, dim3(B), dim3(SEL_T), 0, st, vals, mask, mask_stride, le_thr, use_abs ? 1 : 0, reqs_dev, nreq,
                        out, counts, P);
 }

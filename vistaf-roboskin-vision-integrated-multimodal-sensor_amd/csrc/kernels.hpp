@@ -16,6 +16,7 @@ struct Tiers {
     int fit_capped = 0;        // 0: 128-VGPR column polyfit (default since the march and the flood stopped pinning CUs for milliseconds: 1.49 against 1.79 ms per step); 1: register-capped variant (96 VGPRs, shares a CU with LDS-heavy one-wave kernels)
     int telea_two_tier = 1;     // 1: 111 KB first tier of the window march + full-size retry of the frames it hands back; 0: full size only
     int unwrap_fast = 1;        // 1: frames whose wrapped field is verified path-independent skip the priority flood (k_unwrap_fast.hip); 0: always flood
+    int big_chain = 1;          // 1: frames of 512 x 512 and more take k_big.hip's chains of streaming kernels for the exact selections and the IRLS fits; 0: one workgroup per frame
     int telea_mw = 1;           // 1: the 16-wave window kernel (ordering pass + dataflow fills, k_inpaint_mw.hip) as first tier, single-wave tiers behind it; 0: single-wave tiers only
 };
 
@@ -46,7 +47,7 @@ void launch_count_u8(const uint8_t *m, int *counts, int B, int P, hipStream_t st
 // mask for all frames), finite, and (le_thr ? value <= le_thr[b] : true).
 // reqs[j] >= 0: percentile with q32 = reqs[j];  reqs[j] < 0: median.   out[b*nreq+j], counts[b].
 void launch_select(const float *vals, const uint8_t *mask, size_t mask_stride, const float *le_thr, bool use_abs,
-                   const float *reqs_dev, int nreq, float *out, int *counts, int B, int P, hipStream_t st);
+                   const float *reqs_dev, int nreq, float *out, int *counts, int B, int P, hipStream_t st, void *big_scratch = nullptr);      // big_scratch: k_big.hip's chain for large frames
 
 // ---- k_dft.hip / k_dft_tables.hip ----------------------------------------------------------------
 // carrier of one reference frame (shape_ftp.py:878-913, :930-961)
@@ -123,7 +124,7 @@ void launch_unwrap(const float *wrapped, const float *quality, const uint8_t *ma
 // ---- k_fit.hip --------------------------------------------------------------------------------
 // min_count: fitted (mask & finite) pixels needed (:1103); min_mask_count: mask pixels needed, NaN included (debug_ramp's own gate, :1364)
 void launch_robust_polyfit(const float *z, const uint8_t *mask, int order, int iters, float c, int min_count, int min_mask_count, float *coef_out,
-                           float *resid_out, int B, int h, int w, hipStream_t st, int capped = 1);
+                           float *resid_out, int B, int h, int w, hipStream_t st, int capped = 1, void *big_scratch = nullptr);
 
 // ---- k_holes.hip (hole stage, shape_ftp.py:1153-1204, :1770-1801; live only when reliable_smooth_sigma_px == 0) ----------------------
 void launch_zeroed_keep_nan(const float *detr, const float *bg_med, const uint8_t *reliable, float *hmap, int B, int P, hipStream_t st);
@@ -173,6 +174,14 @@ void launch_fill_scalars(double *scalars, int nscal, const int *rel_count, const
 void launch_mark_empty(const int *rel_count, int32_t *status, int B, hipStream_t st);
 void launch_copy_out(const float *depth, const uint8_t *reliable, const int32_t *status, float *out_h, uint8_t *out_r, int B, int P,
                      hipStream_t st);
+
+// ---- k_big.hip (large frames: selection and IRLS fit as chains of streaming kernels over all pixels of the batch)
+size_t big_scratch_bytes(int B, int h, int w);
+bool big_frames(int B, int P);
+void launch_select_big(const float *vals, const uint8_t *mask, size_t mask_stride, const float *le_thr, bool use_abs, const float *reqs_dev, int nreq,
+                       float *out, int *counts, int B, int P, void *scratch, hipStream_t st);
+void launch_robust_polyfit_big(const float *z, const uint8_t *mask, int order, int iters, float c, int min_count, int min_mask_count, float *coef_out,
+                               float *resid_out, int B, int h, int w, void *scratch, hipStream_t st);
 
 // ---- k_tempmap.hip (map-domain stages of the temperature modality; parity unpinned, see the file)
 struct TmAff { double m[6]; };          // source = M * (x, y, 1): the inverse map cv::warpAffine iterates with

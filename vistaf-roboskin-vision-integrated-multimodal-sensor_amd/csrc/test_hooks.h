@@ -14,6 +14,8 @@ extern "C" {
  *       "telea_two_tier" 1 (default) 111 KB first tier of the window march + full-size retry, 0 full-size march only
  *       "unwrap_fast"  1 (default) frames whose wrapped field is verified path-independent take the parallel integration (k_unwrap_fast.hip)
  *                      instead of the priority flood, 0 always the flood (the parent plane is only produced by the flood)
+ *       "big_chain"    1 (default) large frames (>= 512 x 512): selections and IRLS fits as chains of streaming kernels over the whole batch (k_big.hip),
+ *                      0 one workgroup per frame (k_select / k_robust_polyfit)
  *       "telea_mw"     1 (default) 16-wave window kernel (ordering pass + dataflow fills) in front of the single-wave tiers, 0 single-wave tiers only
  *       "fit_capped"   0 (default) the 128-VGPR column polyfit, 1 the register-capped variant (96 VGPRs) that shares a CU with LDS-heavy one-wave kernels
  *       "keep_planes"   1 also writes the float64 demodulated field of every frame ("field" of vistaf_ftp_get_intermediate) */

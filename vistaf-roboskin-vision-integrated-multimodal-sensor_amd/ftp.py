@@ -277,7 +277,7 @@ class FtpSensor:
 
     def _test_set(self, name: str, value: int):
         """Test hook (csrc/test_hooks.h, not part of the boundary): select a fallback / opt-in kernel tier of a stage
-        ("inpaint_tier", "flood_tier", "chamfer_twopass", "telea_two_tier", "telea_mw", "unwrap_fast", "fit_capped") or keep debug planes ("keep_planes")."""
+        ("inpaint_tier", "flood_tier", "chamfer_twopass", "telea_two_tier", "telea_mw", "unwrap_fast", "big_chain", "fit_capped") or keep debug planes ("keep_planes")."""
         _lib.check(self._lib.vistaf_ftp_test_set(self._h, name.encode(), int(value)))
 
     def masks(self, index: int = 0) -> Dict[str, np.ndarray]:
