@@ -807,3 +807,33 @@ def test_march_generation_overflow_is_handed_back(pkg, cal):
     sensor.predict_batch(frames)
     torch.cuda.synchronize()
     assert np.array_equal(sensor.intermediate("img", 2).cpu().numpy().reshape(2, n, n), img)
+
+
+def test_large_frame_chains_agree_with_one_workgroup_per_frame(pkg, cal):
+    """Frames of 512 x 512 and more take k_big.hip: exact selections and IRLS fits as chains of streaming kernels over all pixels of the batch
+    instead of one workgroup per frame.  The selections are exact in both forms -- thresholds and medians must be the SAME bits --, the fits
+    sum their normal equations in a different (fixed) order, so the maps may differ by float64 summation noise (1e-6 of the peak at most);
+    both forms against the oracle at the usual bar."""
+    n, nb = 512, 2
+    cfg = pkg.FtpConfig.scaled(n)
+    ref, sensor = _sensor(pkg, cal, n, cfg, nb, config=3)
+    frames = pkg.synth.deformed_batch(n, 40, nb, config=3)
+    out = sensor.predict_batch(frames)
+    torch.cuda.synchronize()
+    hm0 = out["height_map_mm"].cpu().numpy().copy()
+    sel0 = {k: sensor.intermediate(k, nb).cpu().numpy().copy() for k in ("thr_hi", "thr_g", "mu", "thr3", "core_thr", "core_med")}
+    rs = O.make_reference_state(ref, *pkg.synth.roi_circle(n), cfg)
+    o0 = O.process_frame(frames[0], rs, cfg, *cal)
+    _check_frame(out, 0, o0, n)
+    sensor._test_set("big_chain", 0)
+    out1 = sensor.predict_batch(frames)
+    torch.cuda.synchronize()
+    hm1 = out1["height_map_mm"].cpu().numpy()
+    _check_frame(out1, 0, o0, n)
+    assert np.array_equal(np.isnan(hm0), np.isnan(hm1))
+    assert float(np.nanmax(np.abs(hm0 - hm1))) <= 1e-6 * float(np.nanmax(np.abs(hm1)))
+    for k in ("thr_hi", "thr_g", "mu"):                      # selections upstream of the fits: identical inputs, exact order statistics
+        assert np.array_equal(sel0[k], sensor.intermediate(k, nb).cpu().numpy()), k
+    for k in ("thr3", "core_thr", "core_med"):               # downstream of the fits: same to the fits' summation noise
+        a, b = sel0[k], sensor.intermediate(k, nb).cpu().numpy()
+        assert np.allclose(a, b, rtol=1e-5, atol=1e-7), k
