@@ -19,12 +19,12 @@ namespace vf {
 constexpr int TQ_CAP = 6144;                 // LDS queue capacity (entries)
 constexpr uint8_t T_KNOWN = 0, T_BAND = 1, T_INSIDE = 2, T_CHANGE = 3, T_SEED = 0x80;   // T_SEED: bit flag, initial band
 
-__device__ inline float ldc(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline float ldc(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 template <bool LF>
 __device__ inline uint8_t ldf(const uint8_t *f, int i)
 {
     if (LF) return f[i];
-    return __hip_atomic_load(f + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load(f + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 __device__ inline void drain() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
@@ -41,7 +41,7 @@ __device__ unsigned long long g_telea_dbg[16];
 #define TSTAMP(i) do { } while (0)
 #endif
 
-__device__ inline uint32_t ldq(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline uint32_t ldq(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 
 struct TQueue {
     uint32_t *T;       // float bits of T (>= 0), ascending in [head, tail)
@@ -404,39 +404,6 @@ __global__ __launch_bounds__(64) void k_telea(float *__restrict__ img_all, const
     (void)bad_all;
 }
 
-// The clusters the LDS windows could not take (k_inpaint_cl.hip: `list` of roots per frame), each on its own wave: blockIdx.x walks the list,
-// blockIdx.y is the frame.  Flags, T and the image are the frame's planes in global memory -- clusters touch disjoint cells --, every slot
-// has its own slice of the frame's queue arrays.  The pop order inside a cluster is the whole-frame queue's (k_inpaint_cl.hip).
-__global__ __launch_bounds__(64) void k_telea_big_clusters(float *__restrict__ img_all, int range, uint8_t *gflags, float *gT, uint32_t *gqueue,
-                                                           const int32_t *__restrict__ labels_all, const int32_t *__restrict__ list_all,
-                                                           const int32_t *__restrict__ count, const int32_t *__restrict__ xmin,
-                                                           const int32_t *__restrict__ ymin, const int32_t *__restrict__ xmax,
-                                                           const int32_t *__restrict__ ymax, int32_t *status, int h, int w)
-{
-    const int lane = threadIdx.x;
-    const size_t b = blockIdx.y;
-    const int er = h + 2, ec = w + 2, en = er * ec, P = h * w;
-    const int ncl = count[b];
-    const int M = range + 1;
-    const int slot_cap = (int)((size_t)en / gridDim.x) & ~63;
-    for (int c = blockIdx.x; c < ncl; c += gridDim.x) {
-        const int rootp = list_all[b * (size_t)P + c];
-        const size_t root = b * (size_t)P + rootp;
-        TQueue q;
-        q.T = gqueue + b * (size_t)en * 2 + (size_t)blockIdx.x * slot_cap;
-        q.idx = q.T + en;
-        q.cap = slot_cap;
-        q.head = q.tail = 0; q.overflow = 0;
-        // bounding box of the cluster's hole pixels (image coordinates) grown by range + 1, in padded coordinates, clipped to the padded frame
-        const TeleaScan sc = {max(0, ymin[root] + 1 - M), min(er - 1, ymax[root] + 1 + M), max(0, xmin[root] + 1 - M), min(ec - 1, xmax[root] + 1 + M),
-                              labels_all + b * (size_t)P, rootp};
-        uint8_t *f = gflags + b * (size_t)en * 2;
-        telea_march_global<false>(img_all + b * (size_t)P, range, f, f + en, gT + b * (size_t)en, q, sc, h, w, lane, b);
-        if (q.overflow && lane == 0) status[b] = 2;
-    }
-}
-
-
 #ifdef VISTAF_DEBUG
 void telea_debug_dump()
 {
@@ -450,7 +417,8 @@ void telea_debug_dump()
 size_t inpaint_scratch_bytes_per_frame(int h, int w)
 {
     size_t en = (size_t)(h + 2) * (w + 2);
-    return en * sizeof(float) + 2 * en + 8 * en /*global queue (large frames)*/ + 64 + 8 + 256;
+    // the whole-frame kernel's planes, or those of the big-cluster kernel (k_inpaint_big.hip): never both in one step
+    return std::max(en * sizeof(float) + 2 * en + 8 * en /*global queue (large frames)*/ + 64 + 8 + 256, inpaint_big_scratch_bytes_per_frame(h, w));
 }
 
 static size_t telea_lds_bytes(int h, int w)
@@ -478,24 +446,6 @@ void launch_inpaint_telea(float *img, const uint8_t *bad, int range, void *scrat
     } else {
         hipLaunchKernelGGL(k_telea<false>, dim3(B), dim3(64), 0, st, img, bad, range, gflags, gT, gqueue, nbad, status, h, w, round_u8 ? 1 : 0);
     }
-}
-
-// The hole pixels of `bad_big` (clusters too large for an LDS window), one wave per cluster, up to 32 waves per frame: same scratch layout as
-// launch_inpaint_telea (flags, T and the queue arrays, which are cut into one slice per wave).
-void launch_inpaint_big_clusters(float *img, const uint8_t *bad_big, int range, void *scratch, int32_t *status, const ClusterPlanes &left, int B, int h,
-                                 int w, hipStream_t st)
-{
-    size_t en = (size_t)(h + 2) * (w + 2);
-    float *gT = (float *)scratch;
-    uint8_t *gflags = (uint8_t *)scratch + (size_t)B * en * sizeof(float);
-    uint32_t *gqueue = (uint32_t *)((((uintptr_t)scratch + (size_t)B * en * sizeof(float) + (size_t)B * en * 2) + 255) & ~(uintptr_t)255);
-    int32_t *nbad = (int32_t *)(gqueue + (size_t)B * en * 2);
-    hipMemsetAsync(nbad, 0, sizeof(int32_t) * B, st);
-    hipLaunchKernelGGL(k_telea_prep, dim3((unsigned)((en + 255) / 256), B), dim3(256), 0, st, bad_big, gflags, gT, nbad, (const int32_t *)nullptr, range, h, w);
-    // waves per frame = slices of the frame's queue arrays: at least 8192 entries each, 4..32 of them
-    const int nslot = (int)std::min<size_t>(32, std::max<size_t>(4, en / 8192));
-    hipLaunchKernelGGL(k_telea_big_clusters, dim3(nslot, B), dim3(64), 0, st, img, range, gflags, gT, gqueue, left.labels, left.list, left.count, left.xmin,
-                       left.ymin, left.xmax, left.ymax, status, h, w);
 }
 
 }  // namespace vf

@@ -81,7 +81,7 @@ size_t inpaint_cl_scratch_bytes_per_frame(int h, int w)
     return P * (1 + 4 + 16 + 4 + 1 + 1) + 64;
 }
 
-bool inpaint_clusters_supported(int range) { return range >= 1 && range + 1 <= 31; }
+bool inpaint_clusters_supported(int range) { return inpaint_big_supported(range); }     // the left-over clusters need k_inpaint_big.hip
 
 int inpaint_cluster_cells_cap();
 void launch_telea_clusters2(float *img, const uint8_t *bad, const int32_t *labels, const int32_t *list, const int32_t *count, const int32_t *xmin,
@@ -124,7 +124,7 @@ void launch_inpaint_clusters(float *img, const uint8_t *bad, int range, void *sc
         // the list of the clusters marched above is dead: it now takes the roots that are left
         (void)hipMemsetAsync(count, 0, (size_t)B * 4, st);
         hipLaunchKernelGGL(k_cluster_list_big, g, dim3(256), 0, st, labels, xmin, big, list, count, h, w);
-        left->labels = labels; left->list = list; left->count = count; left->xmin = xmin; left->ymin = ymin; left->xmax = xmax; left->ymax = ymax;
+        left->dil = dil; left->labels = labels; left->list = list; left->count = count; left->xmin = xmin; left->ymin = ymin; left->xmax = xmax; left->ymax = ymax;
     }
 }
 

@@ -108,8 +108,10 @@ int32_t *launch_inpaint_window(float *img, const uint8_t *bad, int range, void *
 // ---- k_inpaint_cl.hip (cluster-parallel front end; leaves oversized clusters in *bad_big_out) ----------
 size_t inpaint_cl_scratch_bytes_per_frame(int h, int w);
 bool inpaint_clusters_supported(int range);
-struct ClusterPlanes { const int32_t *labels, *list, *count, *xmin, *ymin, *xmax, *ymax; };     // [B, P] planes indexed by component root
-// the clusters the LDS windows left over, each on its own wave over the frame's global planes (k_inpaint.hip: k_telea_big_clusters)
+struct ClusterPlanes { const int32_t *labels, *list, *count, *xmin, *ymin, *xmax, *ymax; const uint8_t *dil; };     // [B, P] planes indexed by component root; dil = hole mask dilated by range + 1
+// the clusters the LDS windows left over, each on its own wave over padded global planes with the queue in LDS (k_inpaint_big.hip)
+size_t inpaint_big_scratch_bytes_per_frame(int h, int w);
+bool inpaint_big_supported(int range);
 void launch_inpaint_big_clusters(float *img, const uint8_t *bad_big, int range, void *scratch, int32_t *status, const ClusterPlanes &left, int B, int h,
                                  int w, hipStream_t st);
 void launch_inpaint_clusters(float *img, const uint8_t *bad, int range, void *scratch, uint8_t **bad_big_out, ClusterPlanes *left, int B, int h, int w,
