@@ -99,10 +99,11 @@ __device__ __attribute__((always_inline)) inline void bg_each(const BgWin &W, co
             if (lv[u] == W.rootp) fn(cell[u], fl[u]);
     }
 }
-// fn(cell) for every seed (initial band pixel) of the cluster in raster order, one after the other (uniform).  The SEED bit of a cell never
-// changes, so the flags of the next chunks may be loaded ahead of the pops of this one.
+// fn(base, pend) for every 64-column chunk of the window that holds seeds (initial band pixels) of the cluster, in raster order:
+// pend = the lanes whose cell base + lane is a seed.  The SEED bit of a cell never changes, so the flags of the next chunks may be loaded
+// ahead of the pops of this one.
 template <class F>
-__device__ __attribute__((always_inline)) inline void bg_seeds(const BgWin &W, const uint8_t *f, int lane, F fn)
+__device__ __attribute__((always_inline)) inline void bg_seed_chunks(const BgWin &W, const uint8_t *f, int lane, F fn)
 {
     for (int k0 = 0; k0 < W.total; k0 += BG_SCAN_U) {
         unsigned long long pend[BG_SCAN_U];
@@ -123,13 +124,9 @@ __device__ __attribute__((always_inline)) inline void bg_seeds(const BgWin &W, c
         static_assert(BG_SCAN_U == 4, "the selects below");
 #pragma nounroll
         for (int u = 0; u < BG_SCAN_U; u++) {                       // not unrolled: fn is the whole per-pop body of a pass
-            unsigned long long m = u == 0 ? pend[0] : u == 1 ? pend[1] : u == 2 ? pend[2] : pend[3];
+            const unsigned long long m = u == 0 ? pend[0] : u == 1 ? pend[1] : u == 2 ? pend[2] : pend[3];
             const int bs = u == 0 ? base[0] : u == 1 ? base[1] : u == 2 ? base[2] : base[3];
-            while (m) {
-                const int l = __ffsll((long long)m) - 1;
-                m &= m - 1ull;
-                fn(bs + l);
-            }
+            if (m) fn(bs, m);
         }
     }
 }
@@ -147,15 +144,28 @@ __device__ __attribute__((always_inline)) inline bool bg_march(const BgWin &W, f
     q.cap = LQ ? BG_QCAP : gq_cap;
     q.ovf = 0;
     wq_init(q);
-    auto push = [&](float T_, int idx_) { wq_push(q, T_, idx_, lane); };
-    // ---- pass 1: outside T field (icvCalcFMM, negate): seeds first in raster order, then the queue
+    // ---- pass 1: outside T field (icvCalcFMM, negate): seeds first in raster order, then the queue, up to four pops per step
+    // (telea_pop_outside4: the row / column split of its distance test is exact as long as cell * pitch < 2^32; else one pop per step)
     {
         const TeleaOutsideConsts oc = telea_outside_consts(lane, W.ew);
-        bg_seeds(W, f, lane, [&](int p) { if (!q.ovf) telea_pop_outside(win, oc, p, true, lane, push); });
-        while (!q.ovf) {
-            const int p = wq_pop(q);
-            if (p < 0) break;
-            telea_pop_outside(win, oc, p, false, lane, push);
+        if ((unsigned long long)W.ew * W.ew * (unsigned long long)(W.h + 2 * W.M) < 0x100000000ull) {
+            FmmFlagState fst{t, f};
+            const uint32_t magic = telea_magic_ww(W.ew);
+            unsigned long long np = 0, ns = 0;
+            bg_seed_chunks(W, f, lane, [&](int base, unsigned long long pend) { telea_fmm_seed_chunk(fst, q, oc, base, pend, W.ew, magic, lane, np, ns); });
+            telea_fmm_queue(fst, q, oc, W.ew, magic, lane, np, ns);
+        } else {
+            auto push1 = [&](float T_, int idx_) { wq_push<false>(q, T_, idx_, lane); };
+            bg_seed_chunks(W, f, lane, [&](int base, unsigned long long pend) {
+                while (pend && !q.ovf) { const int l = __ffsll((long long)pend) - 1; pend &= pend - 1ull; telea_pop_outside(win, oc, base + l, true, lane, push1); }
+            });
+            while (!q.ovf) {
+                if (q.nh > 0) wq_merge<false>(q, lane);
+                if (q.ovf || q.head == q.tail) break;
+                const int p = (int)(uint32_t)q.e[q.head];
+                q.head++;
+                telea_pop_outside(win, oc, p, false, lane, push1);
+            }
         }
     }
     if (q.ovf) return false;
@@ -166,9 +176,16 @@ __device__ __attribute__((always_inline)) inline bool bg_march(const BgWin &W, f
     });
     // ---- pass 2: Telea march (icvTeleaInpaintFMM)
     wq_init(q);
+    auto push = [&](float T_, int idx_) { wq_push(q, T_, idx_, lane); };
     const TeleaMarchConsts mc = telea_march_consts(lane, W.ew, range);
     auto march = [&](auto small) {
-        bg_seeds(W, f, lane, [&](int p) { if (!q.ovf) telea_pop_march<decltype(small)::value>(win, mc, p, false, lane, push); });
+        bg_seed_chunks(W, f, lane, [&](int base, unsigned long long pend) {
+            while (pend && !q.ovf) {
+                const int l = __ffsll((long long)pend) - 1;
+                pend &= pend - 1ull;
+                telea_pop_march<decltype(small)::value>(win, mc, base + l, false, lane, push);
+            }
+        });
         while (!q.ovf) {
             const int p = wq_pop(q);
             if (p < 0) break;

@@ -427,32 +427,33 @@ __device__ __attribute__((always_inline)) inline int telea_pop_outside4(State &s
 // One whole FMM pass on a window: the seeds (cells with W_SEED in the flag bytes, T = 0) pop first in raster order, up to four per step out
 // of the current 64-cell chunk, then the queue -- the next <= 4 entries in order are the first words of the cold run once no hot key
 // precedes them.  np / ns count pops / steps (diagnostics).
+// the seeds of one 64-cell chunk starting at cell `base` (pend = its lanes that hold a seed), up to four per step
 template <class State>
-__device__ __attribute__((always_inline)) inline void telea_fmm_pass(State &st, WQ &q, const uint8_t *f, int cells, int ww, int lane,
-                                                                     unsigned long long &np, unsigned long long &ns)
+__device__ __attribute__((always_inline)) inline void telea_fmm_seed_chunk(State &st, WQ &q, const TeleaOutsideConsts &oc, int base, unsigned long long pend,
+                                                                           int ww, uint32_t magic_ww, int lane, unsigned long long &np, unsigned long long &ns)
 {
-    const TeleaOutsideConsts oc = telea_outside_consts(lane, ww);
-    const uint32_t magic_ww = (uint32_t)(0x100000000ull / (unsigned)ww) + 1u;        // cell / ww == umulhi(cell, magic) for cell < 2^16
-    for (int base = 0; base < cells && !q.ovf; base += 64) {
-        const int li = base + lane;
-        unsigned long long pend = __ballot(li < cells && (f[li] & W_SEED));
-        while (pend && !q.ovf) {
-            int cand[4];
-            unsigned long long rest = pend;
+    while (pend && !q.ovf) {
+        int cand[4];
+        unsigned long long rest = pend;
 #pragma unroll
-            for (int k = 0; k < 4; k++) { cand[k] = base + (int)(__ffsll((long long)rest) - 1); rest &= rest - 1ull; }    // ffs(0) - 1 = -1: masked by n
-            const int npend = __popcll(pend);
-            const uint32_t candT[4] = {0u, 0u, 0u, 0u};
-            const int m = telea_pop_outside4(st, oc, cand, candT, telea_outside_prefix(cand, npend < 4 ? npend : 4, ww, magic_ww), true, lane,
-                                             [](int) {}, [&](float T_, int idx_) { wq_push<false>(q, T_, idx_, lane); });
-            pend &= pend - 1ull;
-            if (m > 1) pend &= pend - 1ull;
-            if (m > 2) pend &= pend - 1ull;
-            if (m > 3) pend &= pend - 1ull;
-            np += m;
-            ns++;
-        }
+        for (int k = 0; k < 4; k++) { cand[k] = base + (int)(__ffsll((long long)rest) - 1); rest &= rest - 1ull; }    // ffs(0) - 1 = -1: masked by n
+        const int npend = __popcll(pend);
+        const uint32_t candT[4] = {0u, 0u, 0u, 0u};
+        const int m = telea_pop_outside4(st, oc, cand, candT, telea_outside_prefix(cand, npend < 4 ? npend : 4, ww, magic_ww), true, lane,
+                                         [](int) {}, [&](float T_, int idx_) { wq_push<false>(q, T_, idx_, lane); });
+        pend &= pend - 1ull;
+        if (m > 1) pend &= pend - 1ull;
+        if (m > 2) pend &= pend - 1ull;
+        if (m > 3) pend &= pend - 1ull;
+        np += m;
+        ns++;
     }
+}
+// the queue of an FMM pass until it is empty: the next <= 4 entries in order are the first words of the cold run once no hot key precedes them
+template <class State>
+__device__ __attribute__((always_inline)) inline void telea_fmm_queue(State &st, WQ &q, const TeleaOutsideConsts &oc, int ww, uint32_t magic_ww, int lane,
+                                                                      unsigned long long &np, unsigned long long &ns)
+{
     while (!q.ovf) {
         int cold_n = q.tail - q.head;
         if (cold_n == 0 && q.nh == 0) break;
@@ -477,6 +478,21 @@ __device__ __attribute__((always_inline)) inline void telea_fmm_pass(State &st, 
         np += m;
         ns++;
     }
+}
+// cell / ww == umulhi(cell, magic) for every cell with cell * ww < 2^32
+__host__ __device__ inline uint32_t telea_magic_ww(int ww) { return (uint32_t)(0x100000000ull / (unsigned)ww) + 1u; }
+
+template <class State>
+__device__ __attribute__((always_inline)) inline void telea_fmm_pass(State &st, WQ &q, const uint8_t *f, int cells, int ww, int lane,
+                                                                     unsigned long long &np, unsigned long long &ns)
+{
+    const TeleaOutsideConsts oc = telea_outside_consts(lane, ww);
+    const uint32_t magic_ww = telea_magic_ww(ww);
+    for (int base = 0; base < cells && !q.ovf; base += 64) {
+        const int li = base + lane;
+        telea_fmm_seed_chunk(st, q, oc, base, __ballot(li < cells && (f[li] & W_SEED)), ww, magic_ww, lane, np, ns);
+    }
+    telea_fmm_queue(st, q, oc, ww, magic_ww, lane, np, ns);
 }
 
 #ifdef VISTAF_DEBUG
