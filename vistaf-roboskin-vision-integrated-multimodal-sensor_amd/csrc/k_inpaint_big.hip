@@ -4,7 +4,7 @@
 // One wave per cluster, as for the LDS windows (k_inpaint_win.hip), and the SAME per-pop code (telea_common.hpp): only the planes are
 // somewhere else.  T, the flag bytes and a copy of the image live in global memory, padded by range + 1 cells on every side so that -- like in
 // an LDS window -- `cell + offset` is always a valid cell and OpenCV's first / last row / column index shifts are read off BORDER flags;
-// the priority queue stays in LDS (64 KB: its pushes and pops are the march's most frequent dependent accesses).  A fill then costs one
+// the priority queue stays in LDS (128 KB: its pushes and pops are the march's most frequent dependent accesses).  A fill then costs one
 // round trip to L2 for all of its reads (they are issued together, telea_pop_march) instead of one per dependent step.
 // The planes are shared by all clusters of a frame: clusters touch disjoint cells (k_inpaint_cl.hip), a wave only ever reads cells its own
 // cluster owns or cells nobody writes, and a wave sees its own global stores in program order.
@@ -14,7 +14,7 @@
 
 namespace vf {
 
-constexpr int BG_QCAP = 8192;        // queue entries in LDS (two marches per CU)
+constexpr int BG_QCAP = 16384;       // queue entries in LDS (128 KB: one march per CU; a batch of native crops has fewer big clusters than the chip has CUs)
 constexpr int BG_MAXPAD = 6;         // planes are padded by range + 1 <= 6 cells
 constexpr int BG_MAXSLOTS = 32;      // waves per frame
 
@@ -227,15 +227,16 @@ __global__ __launch_bounds__(64) void k_telea_big_clusters(float *__restrict__ i
         W.i0 = ymin[root]; W.i1 = ymax[root] + 2 * M; W.j0 = xmin[root]; W.j1 = xmax[root] + 2 * M;
         W.nch = (W.j1 - W.j0 + 64) / 64; W.total = (W.i1 - W.i0 + 1) * W.nch;
         W.M = M; W.ew = ew; W.h = h; W.w = w; W.rootp = rootp; W.lab = labels_all + b * (size_t)P;
-        // queue entries are band cells: ring cells in pass 1, hole pixels in pass 2
+        // Queue entries are band cells: ring cells in pass 1, hole pixels in pass 2.  When even all of them fit the LDS queue it cannot
+        // overflow; a cluster with more cells than that keeps its sorted run in this wave's slice of global memory instead, whose overflow is
+        // detected when it happens (the band is a front, a small fraction of the cells: status 2 if it ever outgrows the slice).
         int nring = 0, nhole = 0;
         bg_each(W, f, lane, [&](int, uint8_t v) { nring += (v & W_ST) == W_INSIDE; nhole += (v & W_HOLE) != 0; });
         for (int o = 32; o; o >>= 1) { nring += __shfl_xor(nring, o, 64); nhole += __shfl_xor(nhole, o, 64); }
         const int need = max(nring, nhole) + 128;                    // + the hot run and the slack of a merge
         bool ok;
         if (need <= BG_QCAP) ok = bg_march<true>(W, t, im, f, bg_lds, gq, gq_cap, range, lane);
-        else if (need <= gq_cap) ok = bg_march<false>(W, t, im, f, bg_lds, gq, gq_cap, range, lane);
-        else ok = false;
+        else ok = bg_march<false>(W, t, im, f, bg_lds, gq, gq_cap, range, lane);
         if (!ok) { if (lane == 0) status[b] = 2; continue; }
         bg_each(W, f, lane, [&](int cell, uint8_t v) {
             if (v & W_HOLE) { const int Y = cell / ew, X = cell - Y * ew; img[(size_t)(Y - M) * w + (X - M)] = im[cell]; }
