@@ -94,6 +94,7 @@ struct vistaf_ftp_handle {
     int *cnt_a, *cnt_valid, *rel_count, *contact_count, *bg_count, *bad_count, *flipped;
     unsigned int *gmax;
     int32_t *status;
+    unsigned long long *cc_best;        // [maxB] largest-component key of launch_cc_largest on large frames
     double *scalars;
     float *req_hi, *req_g, *req_med, *req_amp, *req_contact, *req_core;   // device percentile requests
 
@@ -405,7 +406,7 @@ int vistaf_ftp_create(const vistaf_ftp_config *cfg, int h, int w, int cx, int cy
     TRY(dalloc(hd, &hd->core_thr, mb)); TRY(dalloc(hd, &hd->core_med, mb)); TRY(dalloc(hd, &hd->coef, mb * 6));
     TRY(dalloc(hd, &hd->cnt_a, mb)); TRY(dalloc(hd, &hd->cnt_valid, mb)); TRY(dalloc(hd, &hd->rel_count, mb));
     TRY(dalloc(hd, &hd->contact_count, mb)); TRY(dalloc(hd, &hd->bg_count, mb)); TRY(dalloc(hd, &hd->bad_count, mb));
-    TRY(dalloc(hd, &hd->flipped, mb)); TRY(dalloc(hd, &hd->gmax, mb)); TRY(dalloc(hd, &hd->status, mb));
+    TRY(dalloc(hd, &hd->flipped, mb)); TRY(dalloc(hd, &hd->gmax, mb)); TRY(dalloc(hd, &hd->status, mb)); TRY(dalloc(hd, &hd->cc_best, mb));
     TRY(dalloc(hd, &hd->scalars, mb * VISTAF_NSCALARS));
     TRY(dalloc(hd, &hd->hole_med, mb)); TRY(dalloc(hd, &hd->hole_fill, mb));
     hd->named["mu"] = {hd->mu, sizeof(float)}; hd->named["thr_hi"] = {hd->thr_hi, sizeof(float)}; hd->named["thr_g"] = {hd->thr_g, sizeof(float)};
@@ -552,7 +553,7 @@ static int post_demod(vistaf_ftp_handle *hd, int B, float *d_height_mm, uint8_t 
             }
         }
         launch_cc_label(src, hd->labels, B, h, w, st);
-        launch_cc_largest(hd->labels, hd->area, nullptr, hd->roi, hd->rel2, B, P, st);
+        launch_cc_largest(hd->labels, hd->area, hd->cc_best, hd->roi, hd->rel2, B, P, st);
     }
     if (c.reliable_edge_margin_px > 0) {
         // erode_by_distance (shape_ftp.py:368-377): keep a pixel when its 3x3-chamfer distance to the nearest zero pixel exceeds the margin,

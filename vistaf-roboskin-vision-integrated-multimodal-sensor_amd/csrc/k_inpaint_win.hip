@@ -316,7 +316,7 @@ __global__ __launch_bounds__(64) void k_telea_window_retry(float *__restrict__ i
 // k_telea_window, which then sees only their pixels.
 constexpr int CL2_CELLS = 3072;     // window cells per cluster
 constexpr int CL2_QCAP = 512;       // queue entries per cluster
-constexpr int CL2_SLOTS = 48;       // workgroups per frame (each walks clusters c, c + CL2_SLOTS, ...)
+constexpr int CL2_SLOTS = 48;       // workgroups per frame (each walks clusters c, c + slots, ...); more for small batches, see the launcher
 
 __global__ __launch_bounds__(64) void k_telea_clusters2(float *__restrict__ img_all, const uint8_t *__restrict__ bad_all,
                                                         const int32_t *__restrict__ labels_all, const int32_t *__restrict__ list_all,
@@ -350,7 +350,9 @@ void launch_telea_clusters2(float *img, const uint8_t *bad, const int32_t *label
                             const int32_t *ymin, const int32_t *xmax, const int32_t *ymax, uint8_t *big, int range, int B, int h, int w, hipStream_t st)
 {
     const size_t lds = (size_t)CL2_CELLS * 9 + (size_t)CL2_QCAP * 8 + 256;
-    hipLaunchKernelGGL(k_telea_clusters2, dim3(CL2_SLOTS, B), dim3(64), lds, st, img, bad, labels, list, count, xmin, ymin, xmax, ymax, big, range, h, w);
+    // a native crop has ~500 clusters: with few frames in the batch, more waves per frame (about five 32 KB windows fit a CU)
+    const int slots = std::max(CL2_SLOTS, std::min(512, 1536 / std::max(B, 1)));
+    hipLaunchKernelGGL(k_telea_clusters2, dim3(slots, B), dim3(64), lds, st, img, bad, labels, list, count, xmin, ymin, xmax, ymax, big, range, h, w);
 }
 
 #ifdef VISTAF_DEBUG
