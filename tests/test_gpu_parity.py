@@ -440,6 +440,27 @@ def test_alternative_kernel_tiers_agree(pkg, cal, var, val):
     _check_frame(alt, 0, O.process_frame(frames[0], rs, cfg, *cal), n)
 
 
+def test_big_cluster_march_lds_and_global_queue_agree_with_the_window_march(pkg, cal):
+    """k_inpaint_big.hip (clusters no LDS window takes: padded global planes, per-pop code of the LDS windows) with its queue in LDS and
+    -- test hook `big_queue_lds` = 0 -- in the wave's slice of global memory: the inpainted plane of the cluster front end
+    (`inpaint_tier` = 0; at 224 x 224 the hole pixels are one cluster, far beyond the 3072-cell cluster windows) equals the frame-window
+    march's bit for bit in both variants."""
+    n, nb = 224, 12
+    cfg = pkg.FtpConfig.scaled(n)
+    ref, sensor = _sensor(pkg, cal, n, cfg, nb, config=3)
+    frames = pkg.synth.deformed_batch(n, 300, nb, config=3)
+    sensor.predict_batch(frames)
+    torch.cuda.synchronize()
+    img0 = sensor.intermediate("img", nb).cpu().numpy().copy()
+    sensor._test_set("inpaint_tier", 0)
+    for lds in (1, 0):
+        sensor._test_set("big_queue_lds", lds)
+        out = sensor.predict_batch(frames)
+        torch.cuda.synchronize()
+        assert (out["status"].cpu().numpy() == 0).all()
+        assert np.array_equal(sensor.intermediate("img", nb).cpu().numpy(), img0), "queue in %s" % ("LDS" if lds else "global memory")
+
+
 def test_phase_to_height_constants_variant(pkg, cal):
     """The constants of the reference's offline calibrator (Code/phase_to_height.py:63, :115, no debug_ramp): ROI erosion, a wider
     frontier band and no plane pre-removal, scaled to 224: same parity bar as the default configuration."""

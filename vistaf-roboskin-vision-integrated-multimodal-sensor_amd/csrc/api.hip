@@ -234,7 +234,7 @@ void preprocess(vistaf_ftp_handle *hd, const void *frames, int format, int nfram
                 ClusterPlanes left;
                 launch_inpaint_clusters(hd->img, hd->bad1, range, hd->inpaint_cl_scratch, &bad_big, &left, B, h, w, st);
                 if (timed) hipEventRecord(hd->ev[ST_INPAINT], st);      // (after the LDS cluster pass: its bookkeeping counts as mask work)
-                launch_inpaint_big_clusters(hd->img, bad_big, range, hd->inpaint_scratch, hd->status, left, B, h, w, st);
+                launch_inpaint_big_clusters(hd->img, bad_big, range, hd->inpaint_scratch, hd->status, left, B, h, w, st, hd->tiers.big_queue_lds != 0);
             } else {
                 if (timed && mode == 1) hipEventRecord(hd->ev[ST_INPAINT], st);
                 if (mode != 1) only = launch_inpaint_window(hd->img, seq_mask, range, hd->inpaint_win_scratch, B, h, w, st, timed ? hd->ev[ST_INPAINT] : nullptr,
@@ -812,6 +812,7 @@ int vistaf_ftp_test_set(vistaf_ftp_handle *hd, const char *name, int value)
     else if (n == "telea_two_tier") hd->tiers.telea_two_tier = value != 0;
     else if (n == "fit_capped") hd->tiers.fit_capped = value != 0;
     else if (n == "telea_mw") hd->tiers.telea_mw = value != 0;
+    else if (n == "big_queue_lds") hd->tiers.big_queue_lds = value != 0;
     else if (n == "unwrap_fast") hd->tiers.unwrap_fast = value != 0;
     else if (n == "big_chain") hd->tiers.big_chain = value != 0;
     else if (n == "keep_planes") hd->keep_planes = value != 0;

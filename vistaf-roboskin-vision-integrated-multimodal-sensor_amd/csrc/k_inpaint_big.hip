@@ -207,7 +207,7 @@ __global__ __launch_bounds__(64) void k_telea_big_clusters(float *__restrict__ i
                                                            const int32_t *__restrict__ labels_all, const int32_t *__restrict__ list_all,
                                                            const int32_t *__restrict__ count, const int32_t *__restrict__ xmin,
                                                            const int32_t *__restrict__ ymin, const int32_t *__restrict__ xmax,
-                                                           const int32_t *__restrict__ ymax, int32_t *status, int range, int h, int w, int gq_cap)
+                                                           const int32_t *__restrict__ ymax, int32_t *status, int range, int h, int w, int gq_cap, int lds_cap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char bg_lds[];
     const int lane = threadIdx.x;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(64) void k_telea_big_clusters(float *__restrict__ i
         for (int o = 32; o; o >>= 1) { nring += __shfl_xor(nring, o, 64); nhole += __shfl_xor(nhole, o, 64); }
         const int need = max(nring, nhole) + 128;                    // + the hot run and the slack of a merge
         bool ok;
-        if (need <= BG_QCAP) ok = bg_march<true>(W, t, im, f, bg_lds, gq, gq_cap, range, lane);
+        if (need <= lds_cap) ok = bg_march<true>(W, t, im, f, bg_lds, gq, gq_cap, range, lane);
         else ok = bg_march<false>(W, t, im, f, bg_lds, gq, gq_cap, range, lane);
         if (!ok) { if (lane == 0) status[b] = 2; continue; }
         bg_each(W, f, lane, [&](int cell, uint8_t v) {
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(64) void k_telea_big_clusters(float *__restrict__ i
 
 // The hole pixels of `bad_big` (clusters too large for an LDS window), one wave per cluster, up to 32 waves per frame.
 void launch_inpaint_big_clusters(float *img, const uint8_t *bad_big, int range, void *scratch, int32_t *status, const ClusterPlanes &left, int B, int h,
-                                 int w, hipStream_t st)
+                                 int w, hipStream_t st, bool lds_queue)
 {
     const int M = range + 1;
     const size_t en = (size_t)(h + 2 * M) * (w + 2 * M);
@@ -261,7 +261,7 @@ void launch_inpaint_big_clusters(float *img, const uint8_t *bad_big, int range, 
     const int lds = BG_QCAP * 8 + 256;
     ensure_dyn_lds(lds_once, (const void *)k_telea_big_clusters, lds);
     hipLaunchKernelGGL(k_telea_big_clusters, dim3(nslot, B), dim3(64), lds, st, img, gT, gim, gf, gq, left.labels, left.list, left.count, left.xmin,
-                       left.ymin, left.xmax, left.ymax, status, range, h, w, gq_cap);
+                       left.ymin, left.xmax, left.ymax, status, range, h, w, gq_cap, lds_queue ? BG_QCAP : 0);
 }
 
 }  // namespace vf

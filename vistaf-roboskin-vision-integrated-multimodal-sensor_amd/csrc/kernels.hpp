@@ -17,6 +17,7 @@ struct Tiers {
     int telea_two_tier = 1;     // 1: 111 KB first tier of the window march + full-size retry of the frames it hands back; 0: full size only
     int unwrap_fast = 1;        // 1: frames whose wrapped field is verified path-independent skip the priority flood (k_unwrap_fast.hip); 0: always flood
     int big_chain = 1;          // 1: frames of 512 x 512 and more take k_big.hip's chains of streaming kernels for the exact selections and the IRLS fits; 0: one workgroup per frame
+    int big_queue_lds = 1;      // 1: a big cluster's march keeps its queue in LDS whenever its cell counts bound the queue (k_inpaint_big.hip); 0: always this wave's slice of global memory
     int telea_mw = 1;           // 1: the 16-wave window kernel (ordering pass + dataflow fills, k_inpaint_mw.hip) as first tier, single-wave tiers behind it; 0: single-wave tiers only
 };
 
@@ -113,7 +114,7 @@ struct ClusterPlanes { const int32_t *labels, *list, *count, *xmin, *ymin, *xmax
 size_t inpaint_big_scratch_bytes_per_frame(int h, int w);
 bool inpaint_big_supported(int range);
 void launch_inpaint_big_clusters(float *img, const uint8_t *bad_big, int range, void *scratch, int32_t *status, const ClusterPlanes &left, int B, int h,
-                                 int w, hipStream_t st);
+                                 int w, hipStream_t st, bool lds_queue = true);
 void launch_inpaint_clusters(float *img, const uint8_t *bad, int range, void *scratch, uint8_t **bad_big_out, ClusterPlanes *left, int B, int h, int w,
                              hipStream_t st);
 
