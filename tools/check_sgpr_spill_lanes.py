@@ -19,9 +19,9 @@ def kernel_lines(path, name):
         if not on and l.startswith(name) and l.rstrip().endswith(":") or (not on and l.startswith(name + ":")):
             on = True
         if on:
-            out.append(l.rstrip("\n"))
-            if "s_endpgm" in l:
+            if l.startswith(".Lfunc_end"):           # (not the first s_endpgm: a kernel may end in several places)
                 break
+            out.append(l.rstrip("\n"))
     return out
 
 

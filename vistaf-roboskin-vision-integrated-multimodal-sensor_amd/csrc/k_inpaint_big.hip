@@ -134,14 +134,14 @@ __device__ __attribute__((always_inline)) inline void bg_seed_chunks(const BgWin
 // LQ: the queue's sorted run in LDS (the normal case) or in this wave's slice of global memory.  Returns false when the queue overflowed.
 template <bool LQ>
 __device__ __attribute__((always_inline)) inline bool bg_march(const BgWin &W, float *t, float *im, uint8_t *f, unsigned char *lds, unsigned long long *gq,
-                                                              int gq_cap, int range, int lane)
+                                                              int gq_cap, int lds_cap, int range, int lane)
 {
     TeleaWin win;
     win.t = t; win.im = im; win.f = f; win.ww = W.ew;
     WQ q;
     q.e = LQ ? (unsigned long long *)lds : gq;
-    q.hotL = (uint32_t *)(lds + (size_t)BG_QCAP * 8);
-    q.cap = LQ ? BG_QCAP : gq_cap;
+    q.hotL = (uint32_t *)(lds + (size_t)lds_cap * 8);
+    q.cap = LQ ? lds_cap : gq_cap;
     q.ovf = 0;
     wq_init(q);
     // ---- pass 1: outside T field (icvCalcFMM, negate): seeds first in raster order, then the queue, up to four pops per step
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(64) void k_telea_big_clusters(float *__restrict__ i
                                                            const int32_t *__restrict__ labels_all, const int32_t *__restrict__ list_all,
                                                            const int32_t *__restrict__ count, const int32_t *__restrict__ xmin,
                                                            const int32_t *__restrict__ ymin, const int32_t *__restrict__ xmax,
-                                                           const int32_t *__restrict__ ymax, int32_t *status, int range, int h, int w, int gq_cap, int lds_cap)
+                                                           const int32_t *__restrict__ ymax, int32_t *status, int range, int h, int w, int gq_cap, int lds_cap, int lds_use)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char bg_lds[];
     const int lane = threadIdx.x;
@@ -235,8 +235,8 @@ __global__ __launch_bounds__(64) void k_telea_big_clusters(float *__restrict__ i
         for (int o = 32; o; o >>= 1) { nring += __shfl_xor(nring, o, 64); nhole += __shfl_xor(nhole, o, 64); }
         const int need = max(nring, nhole) + 128;                    // + the hot run and the slack of a merge
         bool ok;
-        if (need <= lds_cap) ok = bg_march<true>(W, t, im, f, bg_lds, gq, gq_cap, range, lane);
-        else ok = bg_march<false>(W, t, im, f, bg_lds, gq, gq_cap, range, lane);
+        if (need <= lds_use) ok = bg_march<true>(W, t, im, f, bg_lds, gq, gq_cap, lds_cap, range, lane);
+        else ok = bg_march<false>(W, t, im, f, bg_lds, gq, gq_cap, lds_cap, range, lane);
         if (!ok) { if (lane == 0) status[b] = 2; continue; }
         bg_each(W, f, lane, [&](int cell, uint8_t v) {
             if (v & W_HOLE) { const int Y = cell / ew, X = cell - Y * ew; img[(size_t)(Y - M) * w + (X - M)] = im[cell]; }
@@ -257,11 +257,13 @@ void launch_inpaint_big_clusters(float *img, const uint8_t *bad_big, int range, 
     unsigned long long *gq = (unsigned long long *)((((uintptr_t)(gf + (size_t)B * en)) + 255) & ~(uintptr_t)255);
     const int nslot = bg_slots(h, w), gq_cap = bg_gq_cap(h, w);
     hipLaunchKernelGGL(k_bg_prep, dim3((unsigned)((en + 255) / 256), B), dim3(256), 0, st, img, bad_big, left.dil, gT, gim, gf, range, h, w);
+    // LDS queue: 16384 entries (128 KB, one march per CU) while the batch has fewer big clusters than the chip has CUs -- a native crop has
+    // about ten --, 8192 (two marches per CU) for larger batches; a cluster whose cell counts exceed the queue takes the global slice
+    const int lds_cap = B <= 16 ? BG_QCAP : BG_QCAP / 2;
     static DynLdsOnce lds_once;
-    const int lds = BG_QCAP * 8 + 256;
-    ensure_dyn_lds(lds_once, (const void *)k_telea_big_clusters, lds);
-    hipLaunchKernelGGL(k_telea_big_clusters, dim3(nslot, B), dim3(64), lds, st, img, gT, gim, gf, gq, left.labels, left.list, left.count, left.xmin,
-                       left.ymin, left.xmax, left.ymax, status, range, h, w, gq_cap, lds_queue ? BG_QCAP : 0);
+    ensure_dyn_lds(lds_once, (const void *)k_telea_big_clusters, BG_QCAP * 8 + 256);
+    hipLaunchKernelGGL(k_telea_big_clusters, dim3(nslot, B), dim3(64), (size_t)lds_cap * 8 + 256, st, img, gT, gim, gf, gq, left.labels, left.list, left.count,
+                       left.xmin, left.ymin, left.xmax, left.ymax, status, range, h, w, gq_cap, lds_cap, lds_queue ? lds_cap : 0);
 }
 
 }  // namespace vf

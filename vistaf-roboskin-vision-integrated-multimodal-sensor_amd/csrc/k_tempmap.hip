@@ -1,7 +1,7 @@
 // Map-domain stages of the temperature modality (Code/temperature_sensor.py:538-640, :705-747): clamp_map, inpaint_temperature_map,
 // fuse_maps_per_pixel, oriented_gaussian_blur_float.  PARITY UNPINNED: the reference tree holds no output of these stages (its
 // temperature_map_*.npy are among the blobs that were not mounted) and the regressors that feed them only exist as pickles; the kernels are
-// checked against oracle/temp_oracle.py's restatement of the source text on synthetic planes.  All streaming, one thread per pixel.
+// checked on synthetic planes against the test suite's CPU restatement of the source text (temp_oracle.py).  All streaming, one thread per pixel.
 #include "kernels.hpp"
 
 namespace vf {
