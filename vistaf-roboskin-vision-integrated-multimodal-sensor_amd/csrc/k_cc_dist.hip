@@ -700,14 +700,17 @@ void launch_chamfer_pair(const uint8_t *src, int32_t *tmp_a, float *dist_a, int3
 {
     int cap = (int)((cap_px + 2) / 0.955) + 2;
     if (cap > h) cap = h;
-    const bool two_pass = (force_twopass || cap > 16 || (size_t)h * w * 2 > 150 * 1024) && w <= 512;
+    // wide bands on wide frames (native crops, band 200 px): the closed form walks up to 2 * cap rows per pixel (0.3 ms per frame, all CUs),
+    // the two-pass kernel a frame's rows once each way on one wave per frame and set (4 ms, all frames side by side): the latter from 16 frames on
+    const bool two_pass = (force_twopass || cap > 16 || (size_t)h * w * 2 > 150 * 1024) && (w <= 512 || (w <= 1280 && cap > 64 && B >= 16));
     if (!two_pass) {
         launch_chamfer(src, false, tmp_a, dist_a, B, h, w, cap_px, st, false);
         launch_chamfer(src, true, tmp_b, dist_b, B, h, w, cap_px, st, false);
         return;
     }
     if (w <= 256) hipLaunchKernelGGL(k_chamfer2<4>, dim3(2 * B), dim3(64), 0, st, src, 0, tmp_a, dist_a, tmp_b, dist_b, B, h, w);
-    else hipLaunchKernelGGL(k_chamfer2<8>, dim3(2 * B), dim3(64), 0, st, src, 0, tmp_a, dist_a, tmp_b, dist_b, B, h, w);
+    else if (w <= 512) hipLaunchKernelGGL(k_chamfer2<8>, dim3(2 * B), dim3(64), 0, st, src, 0, tmp_a, dist_a, tmp_b, dist_b, B, h, w);
+    else hipLaunchKernelGGL(k_chamfer2<20>, dim3(2 * B), dim3(64), 0, st, src, 0, tmp_a, dist_a, tmp_b, dist_b, B, h, w);
 }
 
 __global__ void k_erode_by_dist(const float *__restrict__ dist, const uint8_t *__restrict__ src, float margin, uint8_t *__restrict__ out, size_t n)
