@@ -7,8 +7,8 @@
 //   selection (np.percentile / np.median semantics of select.hpp, same keys, same interpolation):
 //     range (one sweep, or bounds handed in) -> per level: 2048-bucket histogram of the keys in [lo, hi] (LDS histograms per block, merged
 //     with atomics; integer counts, so the result does not depend on the order) -> bucket of the wanted rank -> narrower [lo, hi]; the
-//     bucket width shrinks 32 -> 21 -> 10 -> 0 bits, so three levels always end at ONE key; one more sweep finds the next order statistic
-//     (count of keys <= a, smallest key above a).
+//     bucket width shrinks 32 -> 21 -> 10 -> 0 bits, so three levels always end at ONE key; the next order statistic comes out of that last
+//     level too (its histogram has one bucket per key; its sweep also keeps the smallest key above the range).
 //   robust_polyfit2d (shape_ftp.py:1100-1136): per IRLS step the 21 normal-equation sums as per-block partials reduced in a FIXED order
 //     (deterministic), float64 Cholesky on one thread, then the two medians through the selection above with the residual as the value.
 // Arithmetic per sample, keys, median / percentile interpolation and the residual plane are those of k_fit.hip / select.hpp.
@@ -34,6 +34,7 @@ struct SbFrame { uint32_t n, kmin, kmax, nmask; };
 
 // ---- value sources -------------------------------------------------------------------------------------------------------------------
 struct PlaneSrc {                   // k_select's PlaneGetter
+    static constexpr bool tiled = false;
     const float *v; const uint8_t *m; size_t mstride; const float *le; int use_abs; int P;
     __device__ bool key(size_t b, int i, uint32_t &k) const
     {
@@ -51,25 +52,64 @@ struct FitState {                   // per frame
     float med, csig, zmin, zmax;
     int do_fit, mode, n, pad;
 };
-struct ResidSrc {                   // residual (mode 0) or |residual - med| (mode 1) of the fitted samples, k_fit.hip's arithmetic
-    const float *z; const uint8_t *m; const FitState *fs; int h, w;
-    __device__ bool key(size_t b, int i, uint32_t &k) const
+// residual (mode 0) or |residual - med| (mode 1) of the fitted samples, k_fit.hip's arithmetic.  Tiled sweeps (sb_visit): a thread keeps one
+// image column for SB_PX rows, so the terms that only depend on x -- the normalised coordinate, A(x) = c3 x^2 + c0 x + c2 and
+// B(x) = c4 x + c1 -- are formed once per block instead of once per pixel (with the pixel's row by an integer division on top): a sample is
+// then fit = A + y B + c5 y^2 exactly as in the column kernels of k_fit.hip.
+struct ResidSrc {
+    static constexpr bool tiled = true;
+    const float *z; const uint8_t *m; const FitState *fs; int h, w, tiles_x;
+    struct Col { float At, Bt, c5, med, cyf; int mode; };
+    __device__ Col column(size_t b, int x) const
     {
-        const size_t P = (size_t)h * w;
-        const float zz = z[b * P + i];
-        if (!m[b * P + i] || !finitef(zz)) return false;
         const FitState &s = fs[b];
-        const int y = i / w, x = i - y * w;
-        const float cxf = (float)((w - 1) / 2.0), cyf = (float)((h - 1) / 2.0);
-        const float xn = __fdiv_rn(__fsub_rn((float)x, cxf), cxf), yn = __fdiv_rn(__fsub_rn((float)y, cyf), cyf);
-        const float At = fmaf(s.coef[3], __fmul_rn(xn, xn), fmaf(s.coef[0], xn, s.coef[2])), Bt = fmaf(s.coef[4], xn, s.coef[1]);
-        const float fit = __fadd_rn(fmaf(yn, Bt, At), __fmul_rn(s.coef[5], __fmul_rn(yn, yn)));
+        const float cxf = (float)((w - 1) / 2.0);
+        const float xn = __fdiv_rn(__fsub_rn((float)x, cxf), cxf);
+        Col c;
+        c.At = fmaf(s.coef[3], __fmul_rn(xn, xn), fmaf(s.coef[0], xn, s.coef[2]));
+        c.Bt = fmaf(s.coef[4], xn, s.coef[1]);
+        c.c5 = s.coef[5]; c.med = s.med; c.mode = s.mode; c.cyf = (float)((h - 1) / 2.0);
+        return c;
+    }
+    __device__ bool key(const Col &c, size_t b, int y, int x, uint32_t &k) const
+    {
+        const size_t i = b * (size_t)h * w + (size_t)y * w + x;
+        const float zz = z[i];
+        if (!m[i] || !finitef(zz)) return false;
+        const float yn = __fdiv_rn(__fsub_rn((float)y, c.cyf), c.cyf);
+        const float fit = __fadd_rn(fmaf(yn, c.Bt, c.At), __fmul_rn(c.c5, __fmul_rn(yn, yn)));
         float r = __fsub_rn(zz, fit);
-        if (s.mode) r = fabsf(__fsub_rn(r, s.med));
+        if (c.mode) r = fabsf(__fsub_rn(r, c.med));
         k = f2key(r);
         return true;
     }
 };
+
+// body(key) for every valid pixel of this block's share of frame b: SB_T * SB_PX consecutive pixels, or a tile of SB_T columns x SB_PX rows
+template <class Src, class Body>
+__device__ __attribute__((always_inline)) inline void sb_visit(const Src &src, size_t b, int P, Body body)
+{
+    if constexpr (Src::tiled) {
+        const int ty = blockIdx.x / src.tiles_x, tx = blockIdx.x - ty * src.tiles_x;
+        const int x = tx * SB_T + threadIdx.x, y0 = ty * SB_PX;
+        const bool col_ok = x < src.w;
+        const typename Src::Col c = src.column(b, col_ok ? x : 0);
+#pragma unroll 4
+        for (int u = 0; u < SB_PX; u++) {
+            const int y = y0 + u;
+            uint32_t k;
+            if (col_ok && y < src.h && src.key(c, b, y, x, k)) body(k);
+        }
+    } else {
+        const int i0 = blockIdx.x * SB_T * SB_PX + threadIdx.x;
+#pragma unroll 4
+        for (int u = 0; u < SB_PX; u++) {
+            const int i = i0 + u * SB_T;
+            uint32_t k;
+            if (i < P && src.key(b, i, k)) body(k);
+        }
+    }
+}
 
 // ---- selection kernels ---------------------------------------------------------------------------------------------------------------
 __global__ void k_sb_frame_init(SbFrame *fr, int B)
@@ -85,13 +125,7 @@ __global__ __launch_bounds__(SB_T) void k_sb_minmax(Src src, SbFrame *fr, int P)
     const size_t b = blockIdx.y;
     uint32_t c = 0;
     unsigned long long mn = ~0ull, mx = 0;
-    const int i0 = blockIdx.x * SB_T * SB_PX + threadIdx.x;
-#pragma unroll
-    for (int u = 0; u < SB_PX; u++) {
-        const int i = i0 + u * SB_T;
-        uint32_t k;
-        if (i < P && src.key(b, i, k)) { c++; if (k < mn) mn = k; if (k + 1ull > mx) mx = k + 1ull; }
-    }
+    sb_visit(src, b, P, [&](uint32_t k) { c++; if (k < mn) mn = k; if (k + 1ull > mx) mx = k + 1ull; });
     __syncthreads();
     const uint32_t n = block_sum<uint32_t>(c, s32);
     mn = block_min_u64(mn, s64);
@@ -106,6 +140,7 @@ __global__ void k_sb_setup(SbReq *rq, const SbFrame *fr, const float *reqs, int 
     if (t >= B * nreq) return;
     const int b = t / nreq, j = t - b * nreq;
     SbReq r = {};
+    r.min_gt = 0xFFFFFFFFu;
     const SbFrame f = fr[b];
     r.q = reqs ? reqs[j] : -1.f;
     r.lo = f.kmin; r.hi = f.kmax;
@@ -128,11 +163,14 @@ __global__ void k_sb_setup(SbReq *rq, const SbFrame *fr, const float *reqs, int 
     rq[t] = r;
 }
 
+// At a level whose buckets are one key wide (the last one) the sweep also keeps the smallest key ABOVE the range: the next order statistic
+// when the wanted rank is the last key of the range.
 template <class Src>
-__global__ __launch_bounds__(SB_T) void k_sb_hist(Src src, const SbReq *rq, uint32_t *hist, int nreq, int P)
+__global__ __launch_bounds__(SB_T) void k_sb_hist(Src src, SbReq *rq, uint32_t *hist, int nreq, int P)
 {
     __shared__ uint32_t lh[SB_MAXREQ][SB_NB];
     __shared__ SbReq sr[SB_MAXREQ];
+    __shared__ unsigned long long s64[16];
     const size_t b = blockIdx.y;
     if (threadIdx.x < nreq) sr[threadIdx.x] = rq[b * nreq + threadIdx.x];
     for (int i = threadIdx.x; i < nreq * SB_NB; i += SB_T) (&lh[0][0])[i] = 0;
@@ -140,33 +178,44 @@ __global__ __launch_bounds__(SB_T) void k_sb_hist(Src src, const SbReq *rq, uint
     bool any = false;
     for (int j = 0; j < nreq; j++) any = any || !sr[j].done;
     if (!any) return;
-    const int i0 = blockIdx.x * SB_T * SB_PX + threadIdx.x;
-#pragma unroll 4
-    for (int u = 0; u < SB_PX; u++) {
-        const int i = i0 + u * SB_T;
-        uint32_t k;
-        if (i < P && src.key(b, i, k))
-            for (int j = 0; j < nreq; j++)
-                if (!sr[j].done && k >= sr[j].lo && k <= sr[j].hi) atomicAdd(&lh[j][(k - sr[j].lo) >> sr[j].shift], 1u);
-    }
+    unsigned long long nx[SB_MAXREQ];
+#pragma unroll
+    for (int j = 0; j < SB_MAXREQ; j++) nx[j] = ~0ull;
+    sb_visit(src, b, P, [&](uint32_t k) {
+#pragma unroll
+        for (int j = 0; j < SB_MAXREQ; j++)
+            if (j < nreq && !sr[j].done) {
+                if (k >= sr[j].lo && k <= sr[j].hi) atomicAdd(&lh[j][(k - sr[j].lo) >> sr[j].shift], 1u);
+                else if (k > sr[j].hi && k < nx[j]) nx[j] = k;
+            }
+    });
     __syncthreads();
     for (int i = threadIdx.x; i < nreq * SB_NB; i += SB_T) {
         const uint32_t v = (&lh[0][0])[i];
         if (v) atomicAdd(&hist[(b * nreq) * SB_NB + i], v);
     }
+#pragma unroll
+    for (int j = 0; j < SB_MAXREQ; j++) {
+        if (j >= nreq || sr[j].done || sr[j].shift != 0) continue;          // (uniform)
+        __syncthreads();
+        const unsigned long long mn = block_min_u64(nx[j], s64);
+        if (threadIdx.x == 0 && mn != ~0ull) atomicMin(&rq[b * nreq + j].min_gt, (uint32_t)mn);
+    }
 }
 
-// bucket of the wanted rank -> next level (or the key itself once the buckets are one key wide); clears the histogram again
+// bucket of the wanted rank -> next level; once the buckets are one key wide: the key itself, the number of keys <= it and the next key present
+// (the first non-empty bucket above, else the smallest key above the range from the sweep).  Clears the histogram again.
 __global__ __launch_bounds__(1024) void k_sb_pick(SbReq *rq, uint32_t *hist, int nreq)
 {
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t s_bucket, s_before;
+    __shared__ uint32_t wsum[16], wmin[16];
+    __shared__ uint32_t s_bucket, s_before, s_cnt;
     const size_t b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     for (int j = 0; j < nreq; j++) {
         SbReq &r = rq[b * nreq + j];
         uint32_t *hh = hist + (b * nreq + j) * SB_NB;
         if (r.done) continue;
+        const uint32_t shift = r.shift;
         const uint32_t c0 = hh[2 * tid], c1 = hh[2 * tid + 1];
         hh[2 * tid] = 0; hh[2 * tid + 1] = 0;
         const uint32_t mine = c0 + c1;
@@ -177,57 +226,34 @@ __global__ __launch_bounds__(1024) void k_sb_pick(SbReq *rq, uint32_t *hist, int
         for (int i = 0; i < wid; i++) base += wsum[i];
         const uint32_t excl = base + incl - mine, want = r.k - r.below;
         if (want >= excl && want < excl + mine) {
-            if (want < excl + c0) { s_bucket = 2 * tid; s_before = excl; }
-            else { s_bucket = 2 * tid + 1; s_before = excl + c0; }
+            if (want < excl + c0) { s_bucket = 2 * tid; s_before = excl; s_cnt = c0; }
+            else { s_bucket = 2 * tid + 1; s_before = excl + c0; s_cnt = c1; }
         }
         __syncthreads();
+        uint32_t nb = 0xFFFFFFFFu;                               // first non-empty bucket above the chosen one
+        if (shift == 0) {
+            const uint32_t sb = s_bucket;
+            if (2u * tid > sb && c0) nb = 2u * tid;
+            else if (2u * tid + 1u > sb && c1) nb = 2u * tid + 1u;
+            for (int o = 32; o; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)nb, o, 64); nb = v < nb ? v : nb; }
+            if (lane == 0) wmin[wid] = nb;
+            __syncthreads();
+        }
         if (tid == 0) {
-            const uint32_t shift = r.shift;
             const uint32_t nlo = r.lo + (s_bucket << shift);
             uint32_t nhi = shift ? nlo + ((1u << shift) - 1u) : nlo;
             if (nhi > r.hi || nhi < nlo) nhi = r.hi;
+            const uint32_t lo_old = r.lo;
             r.below += s_before; r.lo = nlo; r.hi = nhi;
-            if (shift == 0) { r.a = nlo; r.done = 1; r.cnt_le = 0; r.min_gt = 0xFFFFFFFFu; }
-            else r.shift = shift > (uint32_t)SB_BITS ? shift - SB_BITS : 0u;
+            if (shift == 0) {
+                uint32_t nbm = 0xFFFFFFFFu;
+                for (int i = 0; i < 16; i++) nbm = wmin[i] < nbm ? wmin[i] : nbm;
+                r.a = nlo; r.done = 1;
+                r.cnt_le = r.below + s_cnt;                      // keys <= a
+                if (nbm != 0xFFFFFFFFu) r.min_gt = lo_old + nbm; // else: the smallest key above the range (k_sb_hist), 0xFFFFFFFF if none
+            } else r.shift = shift > (uint32_t)SB_BITS ? shift - SB_BITS : 0u;
         }
         __syncthreads();
-    }
-}
-
-// the next order statistic: keys <= a counted, smallest key above a
-template <class Src>
-__global__ __launch_bounds__(SB_T) void k_sb_next(Src src, SbReq *rq, int nreq, int P)
-{
-    __shared__ uint32_t s32[16];
-    __shared__ unsigned long long s64[16];
-    const size_t b = blockIdx.y;
-    uint32_t a[SB_MAXREQ], le[SB_MAXREQ];
-    unsigned long long nx[SB_MAXREQ];
-    bool need[SB_MAXREQ], any = false;
-    for (int j = 0; j < SB_MAXREQ; j++) {
-        need[j] = j < nreq && rq[b * nreq + j].done == 1 && rq[b * nreq + j].two != 0;
-        a[j] = need[j] ? rq[b * nreq + j].a : 0; le[j] = 0; nx[j] = ~0ull; any = any || need[j];
-    }
-    if (!any) return;
-    const int i0 = blockIdx.x * SB_T * SB_PX + threadIdx.x;
-#pragma unroll 4
-    for (int u = 0; u < SB_PX; u++) {
-        const int i = i0 + u * SB_T;
-        uint32_t k;
-        if (i < P && src.key(b, i, k))
-#pragma unroll
-            for (int j = 0; j < SB_MAXREQ; j++)
-                if (need[j]) { le[j] += k <= a[j] ? 1u : 0u; if (k > a[j] && k < nx[j]) nx[j] = k; }
-    }
-    for (int j = 0; j < SB_MAXREQ; j++) {
-        if (!need[j]) continue;
-        __syncthreads();
-        const uint32_t tot = block_sum<uint32_t>(le[j], s32);
-        const unsigned long long mn = block_min_u64(nx[j], s64);
-        if (threadIdx.x == 0) {
-            if (tot) atomicAdd(&rq[b * nreq + j].cnt_le, tot);
-            if (mn != ~0ull) atomicMin(&rq[b * nreq + j].min_gt, (uint32_t)mn);
-        }
     }
 }
 
@@ -290,47 +316,53 @@ __global__ void k_fb_init(FitState *fs, const SbFrame *fr, int min_count, int mi
     s.csig = 1.f;
     fs[b] = s;
 }
-// 21 normal-equation sums of the block's samples: weights w = 1 / (1 + (r / csig)^2) (first step: 1), float64 sums of exact products
+// 21 normal-equation sums of the block's samples: weights w = 1 / (1 + (r / csig)^2) (first step: 1), float64 sums of exact products.
+// Blocks are tiles of FB_T columns x FB_PX rows (a thread keeps its column: see ResidSrc).
 __global__ __launch_bounds__(FB_T) void k_fb_sums(const float *__restrict__ z_all, const uint8_t *__restrict__ m_all, const FitState *fs, double *partial,
-                                                  int it, int h, int w)
+                                                  int it, int h, int w, int tiles_x)
 {
     __shared__ double s_part[FB_T / 64][21];
     const size_t b = blockIdx.y;
     const FitState s = fs[b];
     if (!s.do_fit) return;
-    const int P = h * w;
+    const size_t P = (size_t)h * w;
     const float cxf = (float)((w - 1) / 2.0), cyf = (float)((h - 1) / 2.0);
     const float inv_csig = __fdiv_rn(1.0f, s.csig);
     double v[21];
 #pragma unroll
     for (int i = 0; i < 21; i++) v[i] = 0.0;
-    const int i0 = blockIdx.x * FB_T * FB_PX + threadIdx.x;
-    for (int u = 0; u < FB_PX; u++) {
-        const int i = i0 + u * FB_T;
-        if (i >= P) break;
-        const float zz = z_all[b * (size_t)P + i];
-        if (!m_all[b * (size_t)P + i] || !finitef(zz)) continue;
-        const int y = i / w, x = i - y * w;
-        const float xn = __fdiv_rn(__fsub_rn((float)x, cxf), cxf), yn = __fdiv_rn(__fsub_rn((float)y, cyf), cyf);
-        float wt = 1.f;
-        if (it > 0) {
-            const float At = fmaf(s.coef[3], __fmul_rn(xn, xn), fmaf(s.coef[0], xn, s.coef[2])), Bt = fmaf(s.coef[4], xn, s.coef[1]);
-            const float fit = __fadd_rn(fmaf(yn, Bt, At), __fmul_rn(s.coef[5], __fmul_rn(yn, yn)));
-            const float uu = __fmul_rn(__fsub_rn(zz, fit), inv_csig);
-            wt = __fdiv_rn(1.0f, __fadd_rn(1.0f, __fmul_rn(uu, uu)));
-        }
-        const double w2 = (double)wt * (double)wt, xd = xn, yd = yn, zw = w2 * (double)zz;
-        // monomials x^a y^b, b-major with 5, 4, 3, 2, 1 entries (k_fit.hip's index), then the six right-hand sides
-        double yp = w2;
-        int k = 0;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int x = tx * FB_T + threadIdx.x, y0 = ty * FB_PX;
+    if (x < w) {
+        const float xn = __fdiv_rn(__fsub_rn((float)x, cxf), cxf);
+        const float At = fmaf(s.coef[3], __fmul_rn(xn, xn), fmaf(s.coef[0], xn, s.coef[2])), Bt = fmaf(s.coef[4], xn, s.coef[1]);
+        const double xd = xn;
+        for (int u = 0; u < FB_PX; u++) {
+            const int y = y0 + u;
+            if (y >= h) break;
+            const size_t i = b * P + (size_t)y * w + x;
+            const float zz = z_all[i];
+            if (!m_all[i] || !finitef(zz)) continue;
+            const float yn = __fdiv_rn(__fsub_rn((float)y, cyf), cyf);
+            float wt = 1.f;
+            if (it > 0) {
+                const float fit = __fadd_rn(fmaf(yn, Bt, At), __fmul_rn(s.coef[5], __fmul_rn(yn, yn)));
+                const float uu = __fmul_rn(__fsub_rn(zz, fit), inv_csig);
+                wt = __fdiv_rn(1.0f, __fadd_rn(1.0f, __fmul_rn(uu, uu)));
+            }
+            const double w2 = (double)wt * (double)wt, yd = yn, zw = w2 * (double)zz;
+            // monomials x^a y^b, b-major with 5, 4, 3, 2, 1 entries (k_fit.hip's index), then the six right-hand sides
+            double yp = w2;
+            int k = 0;
 #pragma unroll
-        for (int bb = 0; bb <= 4; bb++) {
-            double xp = yp;
+            for (int bb = 0; bb <= 4; bb++) {
+                double xp = yp;
 #pragma unroll
-            for (int aa = 0; aa + bb <= 4; aa++) { v[k++] += xp; xp *= xd; }
-            yp *= yd;
+                for (int aa = 0; aa + bb <= 4; aa++) { v[k++] += xp; xp *= xd; }
+                yp *= yd;
+            }
+            v[15] += zw * xd; v[16] += zw * yd; v[17] += zw; v[18] += zw * xd * xd; v[19] += zw * xd * yd; v[20] += zw * yd * yd;
         }
-        v[15] += zw * xd; v[16] += zw * yd; v[17] += zw; v[18] += zw * xd * xd; v[19] += zw * xd * yd; v[20] += zw * yd * yd;
     }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
@@ -447,18 +479,24 @@ static BigScratch big_carve(void *scratch, int B, int P)
     return s;
 }
 static int sweep_blocks(int P) { return (P + SB_T * SB_PX - 1) / (SB_T * SB_PX); }
+static int tile_blocks(int h, int w) { return ((w + SB_T - 1) / SB_T) * ((h + SB_PX - 1) / SB_PX); }
+template <class Src>
+static int sweep_grid(const Src &src, int P)
+{
+    if constexpr (Src::tiled) return tile_blocks(src.h, src.w);
+    else return sweep_blocks(P);
+}
 
 // the selection proper on a prepared SbFrame (n, kmin, kmax per frame)
 template <class Src>
 static void select_levels(const Src &src, const BigScratch &S, const float *reqs_dev, int nreq, float *out, int *counts, int B, int P, hipStream_t st)
 {
-    const dim3 sweep(sweep_blocks(P), B);
+    const dim3 sweep(sweep_grid(src, P), B);
     hipLaunchKernelGGL(k_sb_setup, dim3((B * nreq + 63) / 64), dim3(64), 0, st, S.rq, S.fr, reqs_dev, nreq, B);
     for (int level = 0; level < 3; level++) {
         hipLaunchKernelGGL((k_sb_hist<Src>), sweep, dim3(SB_T), 0, st, src, S.rq, S.hist, nreq, P);
         hipLaunchKernelGGL(k_sb_pick, dim3(B), dim3(1024), 0, st, S.rq, S.hist, nreq);
     }
-    hipLaunchKernelGGL((k_sb_next<Src>), sweep, dim3(SB_T), 0, st, src, S.rq, nreq, P);
     hipLaunchKernelGGL(k_sb_finish, dim3((B * nreq + 63) / 64), dim3(64), 0, st, S.rq, out, counts, S.fr, nreq, B);
 }
 
@@ -469,7 +507,7 @@ size_t big_scratch_bytes(int B, int h, int w)
     const size_t P = (size_t)h * w;
     return ((((size_t)B * sizeof(SbFrame)) + 255) & ~(size_t)255) + ((((size_t)B * SB_MAXREQ * sizeof(SbReq)) + 255) & ~(size_t)255) +
            (size_t)B * SB_MAXREQ * SB_NB * 4 + ((((size_t)B * sizeof(FitState)) + 255) & ~(size_t)255) +
-           (size_t)B * ((P + FB_T * FB_PX - 1) / (FB_T * FB_PX)) * 21 * sizeof(double) + 1024;
+           (size_t)B * std::max((P + FB_T * FB_PX - 1) / (FB_T * FB_PX), (size_t)tile_blocks(h, w)) * 21 * sizeof(double) + 1024;
 }
 // frames large enough that a batch cannot fill the chip with one workgroup per frame
 bool big_frames(int B, int P) { return P >= 262144 && B <= 192; }
@@ -495,10 +533,12 @@ void launch_robust_polyfit_big(const float *z, const uint8_t *mask, int order, i
     hipLaunchKernelGGL(k_sb_frame_init, dim3((B + 63) / 64), dim3(64), 0, st, S.fr, B);
     hipLaunchKernelGGL(k_fb_count, dim3(nblk, B), dim3(FB_T), 0, st, z, mask, S.fr, P);
     hipLaunchKernelGGL(k_fb_init, dim3((B + 63) / 64), dim3(64), 0, st, S.fs, S.fr, min_count, min_mask_count, B);
-    ResidSrc src{z, mask, S.fs, h, w};
+    static_assert(FB_T == SB_T && FB_PX == SB_PX, "one tile shape");
+    const int tiles_x = (w + SB_T - 1) / SB_T, ntile = tile_blocks(h, w);
+    ResidSrc src{z, mask, S.fs, h, w, tiles_x};
     for (int it = 0; it < iters; it++) {
-        hipLaunchKernelGGL(k_fb_sums, dim3(nblk, B), dim3(FB_T), 0, st, z, mask, S.fs, S.partial, it, h, w);
-        hipLaunchKernelGGL(k_fb_solve, dim3(B), dim3(64), 0, st, S.fs, S.partial, S.fr, nblk, order);
+        hipLaunchKernelGGL(k_fb_sums, dim3(ntile, B), dim3(FB_T), 0, st, z, mask, S.fs, S.partial, it, h, w, tiles_x);
+        hipLaunchKernelGGL(k_fb_solve, dim3(B), dim3(64), 0, st, S.fs, S.partial, S.fr, ntile, order);
         if (it == iters - 1) break;                     // the weights of the last step are never used upstream
         for (int which = 0; which < 2; which++) {
             select_levels(src, S, nullptr, 1, nullptr, nullptr, B, P, st);
