@@ -39,14 +39,14 @@ rows = list(csv.DictReader(open(stats)))
 open(os.path.join(P, f"{rnd}_kernel_stats.csv"), "w").write(open(stats).read())
 with open(os.path.join(P, f"{rnd}_kernel_table.txt"), "w") as f:
     for r in rows[:22]:
-        f.write("%-60s calls %4s avg_us %10.1f  pct %5s\n" % (r["Name"].split("(")[0][-60:], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
+        f.write("%-60s calls %4s avg_us %10.1f  pct %5s\n" % (r["Name"].replace("(anonymous namespace)::", "").split("(")[0][-60:], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
 
 res = collections.defaultdict(dict)
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(newest(f"{G}/pmc_{tag}_{c}/**/*counter_collection.csv"))):
         if r.get("Counter_Name") == c:
-            acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+            acc[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         res[k][c] = sum(v) / len(v)
         res[k]["launches_" + c] = len(v)

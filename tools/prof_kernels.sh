@@ -14,5 +14,5 @@ python3 - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows[:22]:
-    print("%-60s calls %4s avg_us %10.1f  pct %5s" % (r["Name"].split("(")[0][-60:], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
+    print("%-60s calls %4s avg_us %10.1f  pct %5s" % (r["Name"].replace("(anonymous namespace)::", "").split("(")[0][-60:], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
 PY

@@ -21,7 +21,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in fs:
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") == c:
-                acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+                acc[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         res[k][c] = sum(v) / len(v)
         res[k]["launches_" + c] = len(v)
