@@ -372,7 +372,10 @@ def main():
                 "parallelism": f"dp{world}", "inflight_batches": len(sensors), "frames_with_nonzero_status": status_bad,
             },
             "roofline": {
-                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "bound": "hbm",
+                # (the stage names are the library's, fixed per stage: frames beyond the window march's capacity go cluster by cluster)
+                "kernel": dom if n * n <= 8 * 14464 else dom.replace("k_telea_window_mw", "k_telea_clusters2 + k_telea_big_clusters"),
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "kernel_ms": acc[dom], "algorithmic_bytes_per_launch": alg_bytes,
                 "note": {"detrend (3x IRLS)": "three IRLS fits per frame, samples register-resident (one 1024-thread workgroup per frame): ~33 sweeps over "
