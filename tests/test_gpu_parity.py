@@ -461,6 +461,34 @@ def test_big_cluster_march_lds_and_global_queue_agree_with_the_window_march(pkg,
         assert np.array_equal(sensor.intermediate("img", nb).cpu().numpy(), img0), "queue in %s" % ("LDS" if lds else "global memory")
 
 
+@pytest.mark.parametrize("n,nb,shipped", [(224, 48, False), (1182, 2, True)])
+def test_sessions_in_flight_give_the_same_bits_as_alone(pkg, cal, n, nb, shipped):
+    """bench.py's default keeps three sessions in flight, each on its own stream with its own workspace.  Nothing of a session may depend on
+    what else runs on the chip: three sessions with different batches, issued round-robin on three streams for several rounds, must return
+    exactly what each returns alone -- at bench size (window march, one workgroup per frame everywhere) and on native crops (cluster
+    march with 128 KB of LDS per wave, chains of kernels over the batch)."""
+    cfg = pkg.FtpConfig() if shipped else pkg.FtpConfig.scaled(n)
+    sensors, frames, alone = [], [], []
+    for k in range(3):
+        _, s = _sensor(pkg, cal, n, cfg, nb, config=3)
+        f = torch.from_numpy(pkg.synth.deformed_batch(n, 700 + 100 * k, nb, config=3)).cuda()
+        o = s.predict_batch(f)
+        torch.cuda.synchronize()
+        assert (o["status"].cpu().numpy() == 0).all()
+        sensors.append(s); frames.append(f)
+        alone.append({key: o[key].cpu().numpy().copy() for key in ("height_map_mm", "scalars", "output_reliable")})
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    outs = [None] * 3
+    for rnd in range(4):
+        for k in range(3):
+            with torch.cuda.stream(streams[k]):
+                outs[k] = sensors[k].predict_batch(frames[k], outs[k])
+    torch.cuda.synchronize()
+    for k in range(3):
+        for key in alone[k]:
+            assert np.array_equal(outs[k][key].cpu().numpy(), alone[k][key], equal_nan=True), (k, key)
+
+
 def test_phase_to_height_constants_variant(pkg, cal):
     """The constants of the reference's offline calibrator (Code/phase_to_height.py:63, :115, no debug_ramp): ROI erosion, a wider
     frontier band and no plane pre-removal, scaled to 224: same parity bar as the default configuration."""
