@@ -23,12 +23,28 @@ __global__ void k_cluster_bbox(const uint8_t *__restrict__ bad, const int32_t *_
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     size_t b = blockIdx.y;
     int P = h * w;
-    if (p >= P) return;
-    size_t i = b * (size_t)P + p;
-    if (!bad[i]) return;
-    size_t r = b * (size_t)P + labels[i];
+    const bool on = p < P && bad[b * (size_t)P + (p < P ? p : 0)] != 0;
+    const int lab = on ? labels[b * (size_t)P + p] : -1;
     int y = p / w, x = p - y * w;
-    atomicMin(&xmin[r], x); atomicMin(&ymin[r], y); atomicMax(&xmax[r], x); atomicMax(&ymax[r], y);
+    // the hole pixels of a wave (64 consecutive pixels) mostly belong to one cluster: one set of atomics per cluster and wave instead of one
+    // per pixel (the thousands of pixels of a big cluster all hit the same four words)
+    unsigned long long active = __ballot(on);
+    while (active) {
+        const int leader = __ffsll((long long)active) - 1;
+        const int r0 = __builtin_amdgcn_readlane(lab, leader);
+        const unsigned long long same = __ballot(on && lab == r0);
+        const bool mine = on && lab == r0;
+        int x0 = mine ? x : 0x7fffffff, y0 = mine ? y : 0x7fffffff, x1 = mine ? x : -1, y1 = mine ? y : -1;
+        for (int o = 32; o; o >>= 1) {
+            x0 = min(x0, __shfl_xor(x0, o, 64)); y0 = min(y0, __shfl_xor(y0, o, 64));
+            x1 = max(x1, __shfl_xor(x1, o, 64)); y1 = max(y1, __shfl_xor(y1, o, 64));
+        }
+        if ((int)(threadIdx.x & 63) == leader) {
+            const size_t r = b * (size_t)P + r0;
+            atomicMin(&xmin[r], x0); atomicMin(&ymin[r], y0); atomicMax(&xmax[r], x1); atomicMax(&ymax[r], y1);
+        }
+        active &= ~same;
+    }
 }
 
 // list[b*P + k] = root of the k-th cluster of frame b that fits the cluster kernel; big[root] = 1 for the others

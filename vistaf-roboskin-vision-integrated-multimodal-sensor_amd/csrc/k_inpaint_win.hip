@@ -351,7 +351,7 @@ void launch_telea_clusters2(float *img, const uint8_t *bad, const int32_t *label
 {
     const size_t lds = (size_t)CL2_CELLS * 9 + (size_t)CL2_QCAP * 8 + 256;
     // a native crop has ~500 clusters: with few frames in the batch, more waves per frame (about five 32 KB windows fit a CU)
-    const int slots = std::max(CL2_SLOTS, std::min(512, 1536 / std::max(B, 1)));
+    const int slots = std::max(CL2_SLOTS, std::min(512, 4096 / std::max(B, 1)));
     hipLaunchKernelGGL(k_telea_clusters2, dim3(slots, B), dim3(64), lds, st, img, bad, labels, list, count, xmin, ymin, xmax, ymax, big, range, h, w);
 }
 
