@@ -400,6 +400,18 @@ def test_non_square_odd_sizes(pkg, cal):
         s = out["scalars"][b].cpu().numpy()
         assert int(s[4]) == o["argmax_depth_index"]
         assert int(out["status"][b]) == 0
+    # the cluster front end on the same odd-sized frames (LDS cluster windows + the padded global planes of k_inpaint_big.hip, both queue
+    # variants): same inpainted plane, same map
+    img0 = sensor.intermediate("img", 2).cpu().numpy().copy()
+    hm0 = out["height_map_mm"].cpu().numpy().copy()
+    sensor._test_set("inpaint_tier", 0)
+    for lds in (1, 0):
+        sensor._test_set("big_queue_lds", lds)
+        alt = sensor.predict_batch(frames)
+        torch.cuda.synchronize()
+        assert (alt["status"].cpu().numpy() == 0).all()
+        assert np.array_equal(sensor.intermediate("img", 2).cpu().numpy(), img0)
+        assert np.array_equal(alt["height_map_mm"].cpu().numpy(), hm0, equal_nan=True)
 
 
 
