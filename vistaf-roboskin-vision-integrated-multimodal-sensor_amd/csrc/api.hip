@@ -665,7 +665,8 @@ static int post_demod(vistaf_ftp_handle *hd, int B, float *d_height_mm, uint8_t 
     PostParams pp;
     pp.mm_per_px = hd->mm_per_px; pp.depth_eps_mm = c.depth_eps_mm; pp.period_px = hd->period; pp.force_curve = hd->fcurve;
     pp.pair_geom = pair_geom; pp.grating_pitch_mm = c.grating_pitch_mm;
-    launch_tail(hd->depth, nullptr, hd->unitless, hd->roi, pp, hd->scalars, VISTAF_NSCALARS, nullptr, B, P, st);
+    launch_tail(hd->depth, nullptr, hd->unitless, hd->roi, pp, hd->scalars, VISTAF_NSCALARS, nullptr, B, P, st, hd->tiers.big_chain ? hd->big_scratch : nullptr,
+                hd->big_scratch ? big_scratch_bytes(hd->maxB, h, w) : 0);
     launch_fill_scalars(hd->scalars, VISTAF_NSCALARS, hd->rel_count, hd->flipped, hd->amp_thr, hd->thr_used, hd->bg_med, bad_count, B, st);
     launch_copy_out(hd->depth, orel, hd->status, d_height_mm, d_reliable, B, P, st);
     if (d_scalars) HIPCHK(hipMemcpyAsync(d_scalars, hd->scalars, sizeof(double) * VISTAF_NSCALARS * B, hipMemcpyDeviceToDevice, st));

@@ -349,9 +349,112 @@ __global__ __launch_bounds__(1024) void k_tail(const float *__restrict__ height_
         else { S[7] = (double)nanf32(); S[8] = -1.0; }
     }
 }
-void launch_tail(const float *height_mm, const uint8_t *roi_or_null, const float *unitless_or_null, const uint8_t *roi_static,
-                 PostParams pp, double *scalars, int nscal, double *out3_or_null, int B, int P, hipStream_t st)
+// The same tail for frames where one workgroup per frame leaves the chip idle (eight native crops: 1.1 ms): k_tail_part accumulates a block's
+// 4096 pixels exactly as k_tail accumulates a thread's, k_tail_final adds the blocks' partial results up in a fixed order (deterministic;
+// the float64 sums are rounded once to float32 as before) and finishes as k_tail does.
+constexpr int TP_T = 256, TP_PX = 16, TP_WORDS = 10;      // partial record: sp, sn, volp, voln (f64), cntp, cntn, mxp, mxn, am, an (u64)
+__global__ __launch_bounds__(TP_T) void k_tail_part(const float *__restrict__ height_mm, const uint8_t *__restrict__ roi_frame,
+                                                    const float *__restrict__ unitless, const uint8_t *__restrict__ roi_static, float eps, int want_arg,
+                                                    unsigned long long *__restrict__ part, int P)
 {
+    __shared__ double sd[16];
+    __shared__ unsigned long long s64[16];
+    const size_t b = blockIdx.y;
+    const float *H = height_mm + b * (size_t)P;
+    const uint8_t *R = roi_frame ? roi_frame + b * (size_t)P : nullptr;
+    const float *U = unitless ? unitless + b * (size_t)P : nullptr;
+    double sp = 0, sn = 0, volp = 0, voln = 0;
+    unsigned long long cntp = 0, cntn = 0, mxp = 0, mxn = 0, am = 0, an = ~0ull;
+    const int p0 = blockIdx.x * TP_T * TP_PX + threadIdx.x;
+#pragma unroll 4
+    for (int k = 0; k < TP_PX; k++) {
+        const int p = p0 + k * TP_T;
+        if (p >= P) break;
+        const float vv = H[p];
+        const uint8_t rf = R ? R[p] : (uint8_t)0, rs = want_arg ? roi_static[p] : (uint8_t)0;
+        const float uu = U ? U[p] : nanf32();
+        if (vv == vv) { if (vv > 0.f) sp += vv; else sn += -vv; }
+        const bool in = R ? rf != 0 : finitef(vv);
+        float dp = fmaxf(vv, 0.f), dn = fmaxf(-vv, 0.f);
+        if (!in || !finitef(dp)) dp = 0.f;
+        if (!in || !finitef(dn)) dn = 0.f;
+        if (dp > eps) { volp += dp; cntp++; const unsigned long long key = (unsigned long long)__float_as_uint(dp) << 32; if (key > mxp) mxp = key; }
+        if (dn > eps) { voln += dn; cntn++; const unsigned long long key = (unsigned long long)__float_as_uint(dn) << 32; if (key > mxn) mxn = key; }
+        if (rs && finitef(vv)) {
+            const unsigned long long key = ((unsigned long long)f2key(vv) << 32) | (unsigned int)(0xffffffffu - (unsigned int)p);
+            if (key > am) am = key;
+        }
+        if (rs && finitef(uu)) {
+            const unsigned long long key = ((unsigned long long)f2key(uu) << 32) | (unsigned int)p;
+            if (key < an) an = key;
+        }
+    }
+    sp = block_sum<double>(sp, sd); sn = block_sum<double>(sn, sd);
+    volp = block_sum<double>(volp, sd); voln = block_sum<double>(voln, sd);
+    cntp = block_sum<unsigned long long>(cntp, s64); cntn = block_sum<unsigned long long>(cntn, s64);
+    mxp = block_max_u64(mxp, s64); mxn = block_max_u64(mxn, s64);
+    am = block_max_u64(am, s64); an = block_min_u64(an, s64);
+    if (threadIdx.x == 0) {
+        unsigned long long *o = part + (b * gridDim.x + blockIdx.x) * TP_WORDS;
+        o[0] = (unsigned long long)__double_as_longlong(sp); o[1] = (unsigned long long)__double_as_longlong(sn);
+        o[2] = (unsigned long long)__double_as_longlong(volp); o[3] = (unsigned long long)__double_as_longlong(voln);
+        o[4] = cntp; o[5] = cntn; o[6] = mxp; o[7] = mxn; o[8] = am; o[9] = an;
+    }
+}
+__global__ __launch_bounds__(TP_T) void k_tail_final(const unsigned long long *__restrict__ part, int nblk, int has_unitless, PostParams pp,
+                                                     double *__restrict__ scalars, int nscal, double *__restrict__ out3)
+{
+    __shared__ double sd[16];
+    __shared__ unsigned long long s64[16];
+    const size_t b = blockIdx.x;
+    double sp = 0, sn = 0, volp = 0, voln = 0;
+    unsigned long long cntp = 0, cntn = 0, mxp = 0, mxn = 0, am = 0, an = ~0ull;
+    for (int k = threadIdx.x; k < nblk; k += TP_T) {
+        const unsigned long long *o = part + (b * nblk + k) * TP_WORDS;
+        sp += __longlong_as_double((long long)o[0]); sn += __longlong_as_double((long long)o[1]);
+        volp += __longlong_as_double((long long)o[2]); voln += __longlong_as_double((long long)o[3]);
+        cntp += o[4]; cntn += o[5];
+        mxp = o[6] > mxp ? o[6] : mxp; mxn = o[7] > mxn ? o[7] : mxn; am = o[8] > am ? o[8] : am; an = o[9] < an ? o[9] : an;
+    }
+    sp = block_sum<double>(sp, sd);
+    sn = block_sum<double>(sn, sd);
+    const bool use_neg = (float)sn > (float)sp;
+    const double vol = block_sum<double>(use_neg ? voln : volp, sd);
+    const double cntd = (double)block_sum<unsigned long long>(use_neg ? cntn : cntp, s64);
+    const unsigned long long mx = block_max_u64(use_neg ? mxn : mxp, s64);
+    double period_px = pp.period_px, mm_per_px = pp.mm_per_px;
+    if (pp.pair_geom) { period_px = pp.pair_geom[b].period; mm_per_px = period_px > 1e-12 ? pp.grating_pitch_mm / period_px : 0.0; }
+    const double area_px = mm_per_px * mm_per_px;
+    const double volume_cm3 = cntd > 0 ? (double)(float)vol * area_px / 1000.0 : 0.0;
+    const double area_mm2 = cntd * area_px;
+    const double maxd = cntd > 0 ? (double)__uint_as_float((unsigned int)(mx >> 32)) : 0.0;
+    if (out3 && threadIdx.x == 0) { out3[b * 3] = volume_cm3; out3[b * 3 + 1] = area_mm2; out3[b * 3 + 2] = maxd; }
+    if (!scalars) return;
+    am = block_max_u64(am, s64);
+    an = block_min_u64(an, s64);
+    if (threadIdx.x == 0) {
+        double *S = scalars + b * (size_t)nscal;
+        S[0] = volume_cm3; S[1] = area_mm2; S[2] = maxd;
+        S[3] = curve_eval(pp.force_curve, volume_cm3);
+        S[4] = am ? (double)(0xffffffffu - (unsigned int)(am & 0xffffffffu)) : -1.0;
+        S[5] = period_px; S[6] = mm_per_px;
+        if (has_unitless && an != ~0ull) { S[7] = (double)key2f((unsigned int)(an >> 32)); S[8] = (double)(unsigned int)(an & 0xffffffffu); }
+        else { S[7] = (double)nanf32(); S[8] = -1.0; }
+    }
+}
+
+// scratch (optional): room for the per-block records of the chain above, `scratch_bytes` long; without it, or for small frames: k_tail
+void launch_tail(const float *height_mm, const uint8_t *roi_or_null, const float *unitless_or_null, const uint8_t *roi_static,
+                 PostParams pp, double *scalars, int nscal, double *out3_or_null, int B, int P, hipStream_t st, void *scratch, size_t scratch_bytes)
+{
+    const int nblk = (P + TP_T * TP_PX - 1) / (TP_T * TP_PX);
+    if (scratch && P >= 262144 && B <= 192 && (size_t)B * nblk * TP_WORDS * 8 <= scratch_bytes) {
+        unsigned long long *part = (unsigned long long *)scratch;
+        hipLaunchKernelGGL(k_tail_part, dim3(nblk, B), dim3(TP_T), 0, st, height_mm, roi_or_null, unitless_or_null, roi_static, (float)pp.depth_eps_mm,
+                           scalars != nullptr ? 1 : 0, part, P);
+        hipLaunchKernelGGL(k_tail_final, dim3(B), dim3(TP_T), 0, st, part, nblk, unitless_or_null != nullptr ? 1 : 0, pp, scalars, nscal, out3_or_null);
+        return;
+    }
     hipLaunchKernelGGL(k_tail, dim3(B), dim3(1024), 0, st, height_mm, roi_or_null, unitless_or_null, roi_static, pp, scalars, nscal,
                        out3_or_null, P);
 }

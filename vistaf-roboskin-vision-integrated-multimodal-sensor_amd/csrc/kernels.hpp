@@ -171,7 +171,8 @@ void launch_blob_filter(float *depth, const uint8_t *cand, const int32_t *labels
                         const unsigned int *gmax_bits, float min_peak_mm, double rel_frac, uint8_t *kept, int B, int P,
                         hipStream_t st);
 void launch_tail(const float *height_mm, const uint8_t *roi_or_null, const float *unitless_or_null, const uint8_t *roi_static,
-                 PostParams pp, double *scalars, int nscal, double *out3_or_null, int B, int P, hipStream_t st);
+                 PostParams pp, double *scalars, int nscal, double *out3_or_null, int B, int P, hipStream_t st, void *scratch = nullptr,
+                 size_t scratch_bytes = 0);
 void launch_fill_scalars(double *scalars, int nscal, const int *rel_count, const int *flipped, const float *amp_thr,
                          const float *contact_thr, const float *bg_med, const int *bad_count, int B, hipStream_t st);
 void launch_mark_empty(const int *rel_count, int32_t *status, int B, hipStream_t st);
