@@ -367,6 +367,15 @@ def test_native_size_1182_as_shipped(pkg, cal):
     assert abs(pg[0] - po[0]) <= 1e-9 and abs(pg[1] - po[1]) <= 1e-9             # float64 log-parabolic refinement
     o = O.process_frame(frame, rs, cfg, *cal)
     _check_frame(out, 0, o, n)
+    # batches of 16 native crops and more take the one-wave two-pass chamfer (k_chamfer2<20>) for the 200 px frontier band instead of
+    # the closed form: forced here on the single frame (test hook `chamfer_twopass`), same map and scalars
+    hm0, sc0 = out["height_map_mm"].cpu().numpy().copy(), out["scalars"].cpu().numpy().copy()
+    sensor._test_set("chamfer_twopass", 1)
+    alt = sensor.predict_batch(frame[None])
+    torch.cuda.synchronize()
+    assert int(alt["status"][0]) == 0
+    assert np.array_equal(alt["height_map_mm"].cpu().numpy(), hm0, equal_nan=True)
+    assert np.array_equal(alt["scalars"].cpu().numpy(), sc0)
 
 
 def test_non_square_odd_sizes(pkg, cal):

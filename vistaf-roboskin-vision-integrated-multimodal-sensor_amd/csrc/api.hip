@@ -224,8 +224,8 @@ void preprocess(vistaf_ftp_handle *hd, const void *frames, int format, int nfram
             // back; 1: whole-frame kernel only; 0: cluster by cluster -- every independent cluster of hole pixels on its own wave, in an LDS
             // window when it fits, on the frame's global planes otherwise.  At 224 x 224 the hole pixels form ONE cluster per frame, so the
             // frame window is the better tool; frames much larger than its capacity (14 464 cells) -- the native 1182 x 1182 crops -- never
-            // fit one window, and there the crests are ~60 px apart: many independent clusters (march at native size: 1.95 s per batch with
-            // the whole-frame kernel, 0.54 s with LDS clusters + whole-frame kernel for the rest, see DESIGN.md section 9 for the current figure).
+            // fit one window, and there the crests are ~60 px apart: many independent clusters (march of eight native crops: 1.95 s with the
+            // whole-frame kernel, 0.54 s with LDS clusters + whole-frame kernel for the rest, 18 ms since k_inpaint_big.hip: DESIGN.md section 5a).
             int mode = hd->tiers.inpaint;
             if (mode == 2 && (size_t)h * w > (size_t)8 * 14464) mode = 0;
             if (mode == 0 && inpaint_clusters_supported(range)) {

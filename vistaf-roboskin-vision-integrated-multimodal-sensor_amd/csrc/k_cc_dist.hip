@@ -702,7 +702,7 @@ void launch_chamfer_pair(const uint8_t *src, int32_t *tmp_a, float *dist_a, int3
     if (cap > h) cap = h;
     // wide bands on wide frames (native crops, band 200 px): the closed form walks up to 2 * cap rows per pixel (0.3 ms per frame, all CUs),
     // the two-pass kernel a frame's rows once each way on one wave per frame and set (4 ms, all frames side by side): the latter from 16 frames on
-    const bool two_pass = (force_twopass || cap > 16 || (size_t)h * w * 2 > 150 * 1024) && (w <= 512 || (w <= 1280 && cap > 64 && B >= 16));
+    const bool two_pass = (force_twopass || cap > 16 || (size_t)h * w * 2 > 150 * 1024) && (w <= 512 || (w <= 1280 && cap > 64 && (B >= 16 || force_twopass)));
     if (!two_pass) {
         launch_chamfer(src, false, tmp_a, dist_a, B, h, w, cap_px, st, false);
         launch_chamfer(src, true, tmp_b, dist_b, B, h, w, cap_px, st, false);
